@@ -1,0 +1,174 @@
+"""ctypes binding of the C ABI declared in include/catfish_hip.h.
+
+The product path has NO CPU fallback: if the HIP library has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or
+``python -m catfish_amd.build``) importing a symbol from here raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcatfish_hip.so")
+
+CF_OK = 0
+CF_ERR_INVALID = -1
+CF_ERR_HIP = -2
+CF_ERR_NOMEM = -3
+CF_WINDOW = 35
+CF_PROF_SLOTS = 8
+
+_f32p = C.POINTER(C.c_float)
+
+
+class cf_hparams(C.Structure):
+    _fields_ = [("layer_size", C.c_int32), ("n_layers", C.c_int32),
+                ("layer_size_res", C.c_int32), ("n_layers_res", C.c_int32),
+                ("window", C.c_int32), ("bn_epsilon", C.c_float),
+                ("max_windows_per_pass", C.c_int64)]
+
+
+class cf_conv_bn(C.Structure):
+    _fields_ = [("kernel", _f32p), ("bias", _f32p), ("gamma", _f32p), ("beta", _f32p),
+                ("moving_mean", _f32p), ("moving_variance", _f32p),
+                ("ksize", C.c_int32), ("cin", C.c_int32)]
+
+
+class cf_gru_dir(C.Structure):
+    _fields_ = [("gates_kernel", _f32p), ("gates_bias", _f32p),
+                ("candidate_kernel", _f32p), ("candidate_bias", _f32p),
+                ("cin", C.c_int32)]
+
+
+class cf_weights(C.Structure):
+    _fields_ = [("conv", C.POINTER(cf_conv_bn)), ("gru", C.POINTER(cf_gru_dir)),
+                ("dense_kernel", _f32p), ("dense_bias", _f32p)]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class CatfishHipError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "catfish_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/catfish_hip.h declares
+SYMBOLS = {
+    "cf_model_create": (C.c_int, [C.POINTER(cf_weights), C.POINTER(cf_hparams), C.c_int, C.POINTER(C.c_void_p)]),
+    "cf_model_destroy": (None, [C.c_void_p]),
+    "cf_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cf_infer_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cf_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int32,
+                                 C.c_void_p, C.c_void_p]),
+    "cf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "cf_profile_reset": (C.c_int, [C.c_void_p]),
+    "cf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "cf_profile_slot_name": (C.c_char_p, [C.c_int]),
+    "cf_debug_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "cf_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "cf_last_error": (C.c_char_p, []),
+    "cf_version": (C.c_char_p, []),
+}
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                "%s not found: the HIP extension has not been built. Run "
+                "`python -m catfish_amd.build` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != CF_OK:
+        msg = lib().cf_last_error().decode("utf-8", "replace")
+        if rc == CF_ERR_INVALID:
+            raise ValueError("catfish_hip: " + msg)
+        raise CatfishHipError(rc, msg)
+
+
+def _as_f32(a):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    return arr, arr.ctypes.data_as(_f32p)
+
+
+def conv_name(j):
+    return "conv1d" if j == 0 else "conv1d_%d" % j
+
+
+def bn_name(j):
+    return "batch_normalization" if j == 0 else "batch_normalization_%d" % j
+
+
+def gru_prefix(layer, direction):
+    return "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell" % (layer, direction)
+
+
+def build_weight_structs(weights, n_layers, n_layers_res):
+    """dict {TF variable name: array} -> (cf_weights, keepalive list).
+
+    Variable names are the ones TF auto-assigns while RNN.__init__ builds the
+    graph (reference rnn_class.py:37-39, resnet_class.py:17-25).
+    """
+    keep = []
+
+    def ptr(name):
+        if name not in weights:
+            raise ValueError("checkpoint is missing tensor %r" % name)
+        arr, p = _as_f32(weights[name])
+        keep.append(arr)
+        return arr, p
+
+    convs = (cf_conv_bn * max(1, 4 * n_layers_res))()
+    for j in range(4 * n_layers_res):
+        k_arr, k_ptr = ptr(conv_name(j) + "/kernel")
+        if k_arr.ndim != 3:
+            raise ValueError("%s/kernel must be [K, Cin, Cout]" % conv_name(j))
+        c = convs[j]
+        c.kernel = k_ptr
+        c.bias = ptr(conv_name(j) + "/bias")[1]
+        c.gamma = ptr(bn_name(j) + "/gamma")[1]
+        c.beta = ptr(bn_name(j) + "/beta")[1]
+        c.moving_mean = ptr(bn_name(j) + "/moving_mean")[1]
+        c.moving_variance = ptr(bn_name(j) + "/moving_variance")[1]
+        c.ksize = k_arr.shape[0]
+        c.cin = k_arr.shape[1]
+    grus = (cf_gru_dir * (2 * n_layers))()
+    for layer in range(n_layers):
+        for d, dname in enumerate(("fw", "bw")):
+            p = gru_prefix(layer, dname)
+            gk_arr, gk_ptr = ptr(p + "/gates/kernel")
+            ck_arr, ck_ptr = ptr(p + "/candidate/kernel")
+            g = grus[2 * layer + d]
+            g.gates_kernel = gk_ptr
+            g.gates_bias = ptr(p + "/gates/bias")[1]
+            g.candidate_kernel = ck_ptr
+            g.candidate_bias = ptr(p + "/candidate/bias")[1]
+            h = ck_arr.shape[1]
+            if gk_arr.shape != (ck_arr.shape[0], 2 * h):
+                raise ValueError("%s: gates/candidate kernel shapes disagree" % p)
+            g.cin = ck_arr.shape[0] - h
+    w = cf_weights()
+    w.conv = convs
+    w.gru = grus
+    w.dense_kernel = ptr("final_fully_connected/kernel")[1]
+    w.dense_bias = ptr("final_fully_connected/bias")[1]
+    keep.extend([convs, grus])
+    return w, keep

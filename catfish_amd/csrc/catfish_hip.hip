@@ -1,0 +1,831 @@
+// catfish_hip.hip -- hand-written CDNA4 (gfx950) kernels + C ABI for the
+// homopolymer-calling forward pass (see include/catfish_hip.h for the
+// reference call this replaces: catfish/models/rnn_class.py:214-216).
+//
+// Design (DESIGN.md has the long version):
+//   * The unit of work is a TILE of 16 windows (35 samples each).  Windows are
+//     independent (zero GRU state, window-local SAME padding:
+//     rnn_class.py:159,170-171; infer.py:43), so a wave owns a tile for a whole
+//     layer and never synchronises with another wave.
+//   * Every matmul is D[feature][window] = W^T * X on v_mfma_f32_16x16x4_f32
+//     (exact fp32, k-ordered fma chain).  Weights are the A operand, read from
+//     LDS in pre-packed fragment order; activations are the B operand.
+//   * The D register layout (col = lane&15 = window, row = 4*(lane>>4)+reg =
+//     feature) is ALSO a valid B-operand layout when the k index is permuted:
+//     register r of M-tile m is k-step 4m+r carrying features {16m+4q+r}.
+//     The weight packer applies the same permutation, so the recurrent state,
+//     r*h and the conv intermediates feed the next MFMA straight from
+//     registers: no LDS round trip, no cross-lane traffic on the serial chain.
+//   * Inter-layer activations live in HBM in that same "fragment" order
+//     [tile][t][mtile][lane][4], so every load/store is a coalesced 16 B/lane
+//     (1 KiB per wave-instruction) access.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include <string>
+#include <cmath>
+
+#include "../../include/catfish_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CF_T 35          // window length (rnn_class.py:27)
+#define CF_H 64          // GRU units per direction of the shipped model
+#define CF_C 32          // conv channels of the shipped model
+#define CF_TILE 16       // windows per tile = MFMA N
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cf_sigmoid(float x) {
+    // tf.nn.sigmoid; v_exp_f32 + v_rcp_f32 (1 ulp each), saturates correctly at +-inf
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float cf_tanh(float x) {
+    // tanh(x) = 1 - 2 / (1 + exp(2x)); absolute error ~1e-7
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f);
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    f32x4 o;
+    o.x = fmaxf(v.x, 0.f); o.y = fmaxf(v.y, 0.f); o.z = fmaxf(v.z, 0.f); o.w = fmaxf(v.w, 0.f);
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Packed-weight geometry shared by host packer and kernels
+// ------------------------------------------------------------------------------------------
+// GRU direction-layer blob (floats):
+//   X  region: [ks < CIN/4][g < 3][lane][j < 4]   A fragments of output M-tile 4g+j, k-step ks (x rows)
+//   HG region: [ks < 16][g < 2][lane][j]          gates (r,u) M-tiles 0..7, h rows
+//   HC region: [ks < 16][lane][j]                 candidate M-tiles 8..11, h rows (multiply r*h)
+//   BIAS     : [mo < 12][q < 4][r < 4]            bias of feature 16mo+4q+r   (gates | candidate)
+//   DENSE    : [m < 4][q][r]                      final_fully_connected weight of this direction
+// Output M-tiles: 0..3 = r gate, 4..7 = u gate, 8..11 = candidate.
+__host__ __device__ constexpr int gru_x_floats(int cin) { return (cin / 4) * 3 * 256; }
+__host__ __device__ constexpr int gru_hg_floats() { return 16 * 2 * 256; }
+__host__ __device__ constexpr int gru_hc_floats() { return 16 * 256; }
+__host__ __device__ constexpr int gru_bias_off(int cin) { return gru_x_floats(cin) + gru_hg_floats() + gru_hc_floats(); }
+__host__ __device__ constexpr int gru_dense_off(int cin) { return gru_bias_off(cin) + 192; }
+__host__ __device__ constexpr int gru_pack_floats(int cin) { return gru_dense_off(cin) + 64; }
+
+// Residual-block blob (floats): NU 32x32 units of 1024 floats [ks < 8][lane][mo < 2], then
+// bias vectors of 32 floats each in [mo][q][r] order.
+//   first block (Cin = 1): units {c3 tap0, tap1, tap2, last}; vectors {b_c3, b_last, w_sc, b_sc, w_first, b_first}
+//   other blocks          : units {sc, first, c3 tap0, tap1, tap2, last}; vectors {b_sc, b_first, b_c3, b_last}
+__host__ __device__ constexpr int res_units(bool first) { return first ? 4 : 6; }
+__host__ __device__ constexpr int res_vecs(bool first) { return first ? 6 : 4; }
+__host__ __device__ constexpr int res_pack_floats(bool first) { return res_units(first) * 1024 + res_vecs(first) * 32; }
+
+// feature carried by lane-quarter q in k-step ks (== register ks&3 of M-tile ks>>2 of a D tile)
+__host__ __device__ constexpr int frag_feature(int ks, int q) { return 16 * (ks >> 2) + 4 * q + (ks & 3); }
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1: residual block (resnet_class.py:44-82), BN folded into the convs.
+// One wave = one tile of 16 windows, streamed over t with a one-step lookahead
+// for the k=3 conv (zero padding at both window edges).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unit_mma(const float* __restrict__ unit, int lane, const f32x4 (&in)[2], f32x4 (&acc)[2]) {
+    const f32x2* u2 = reinterpret_cast<const f32x2*>(unit) + lane;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const f32x2 a = u2[ks * 64];
+        const float b = in[ks >> 2][ks & 3];
+        acc[0] = MFMA16(a.x, b, acc[0]);
+        acc[1] = MFMA16(a.y, b, acc[1]);
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict__ wpack,
+                                                        const float* __restrict__ x_nat,   // FIRST: [n_windows, 35]
+                                                        const f32x4* __restrict__ x_frag,  // !FIRST: [tile][t][2][lane]
+                                                        f32x4* __restrict__ y_frag,        // [tile][t][2][lane]
+                                                        int64_t n_windows, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK = res_pack_floats(FIRST);
+    constexpr int VEC0 = res_units(FIRST) * 1024;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < PACK / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4;
+    const int waves_per_block = blockDim.x >> 6;
+    float* xs = lds + PACK + wave * (CF_TILE * CF_T);  // FIRST only: this wave's x tile [16][35]
+
+    auto vec = [&](int v, int mo) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(lds + VEC0 + v * 32 + mo * 16 + q * 4);
+    };
+
+    for (int tile = blockIdx.x * waves_per_block + wave; tile < n_tiles; tile += gridDim.x * waves_per_block) {
+        f32x4 w_sc[2], b_sc[2], w_f[2], b_f[2];
+        if constexpr (FIRST) {
+            // stage the tile's raw samples: 16 windows x 35 = 560 contiguous floats
+            const int64_t base = (int64_t)tile * CF_TILE * CF_T;
+            const int64_t limit = n_windows * CF_T;
+            for (int i = lane; i < CF_TILE * CF_T; i += 64) xs[i] = (base + i < limit) ? x_nat[base + i] : 0.f;
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo) { w_sc[mo] = vec(2, mo); b_sc[mo] = vec(3, mo); w_f[mo] = vec(4, mo); b_f[mo] = vec(5, mo); }
+            // xs is private to this wave: a wave-level fence orders its ds_writes before the reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        f32x4 o1_pp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        f32x4 o1_p[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        f32x4 sc_p[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int i = 0; i <= CF_T; ++i) {
+            f32x4 o1_c[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            f32x4 sc_c[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            if (i < CF_T) {
+                if constexpr (FIRST) {
+                    // Cin = 1: conv1d is a rank-1 update (resnet_class.py:60,64)
+                    const float xv = xs[(lane & 15) * CF_T + i];
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo) {
+                        sc_c[mo] = w_sc[mo] * xv + b_sc[mo];
+                        o1_c[mo] = relu4(w_f[mo] * xv + b_f[mo]);
+                    }
+                } else {
+                    f32x4 in[2];
+                    const f32x4* src = x_frag + ((int64_t)tile * CF_T + i) * 2 * 64 + lane;
+                    in[0] = src[0];
+                    in[1] = src[64];
+                    sc_c[0] = vec(0, 0); sc_c[1] = vec(0, 1);
+                    unit_mma(lds + 0 * 1024, lane, in, sc_c);                 // shortcut, no relu (:60-61)
+                    f32x4 acc[2] = {vec(1, 0), vec(1, 1)};
+                    unit_mma(lds + 1 * 1024, lane, in, acc);                  // first conv (:64-66)
+                    o1_c[0] = relu4(acc[0]); o1_c[1] = relu4(acc[1]);
+                }
+            }
+            if (i >= 1) {
+                constexpr int U3 = FIRST ? 0 : 2;      // first k=3 tap unit
+                constexpr int VB3 = FIRST ? 0 : 2;     // bias vector of the k=3 conv
+                f32x4 acc[2] = {vec(VB3, 0), vec(VB3, 1)};
+                unit_mma(lds + (U3 + 0) * 1024, lane, o1_pp, acc);            // tap 0 * o1[t-1]
+                unit_mma(lds + (U3 + 1) * 1024, lane, o1_p, acc);             // tap 1 * o1[t]
+                unit_mma(lds + (U3 + 2) * 1024, lane, o1_c, acc);             // tap 2 * o1[t+1]
+                f32x4 o2[2] = {relu4(acc[0]), relu4(acc[1])};                 // (:69-71)
+                f32x4 acc3[2] = {vec(VB3 + 1, 0), vec(VB3 + 1, 1)};
+                unit_mma(lds + (U3 + 3) * 1024, lane, o2, acc3);              // last conv (:74-76)
+                f32x4* dst = y_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
+                dst[0] = relu4(relu4(acc3[0]) + sc_p[0]);                     // add + relu (:79-80)
+                dst[64] = relu4(relu4(acc3[1]) + sc_p[1]);
+            }
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo) { o1_pp[mo] = o1_p[mo]; o1_p[mo] = o1_c[mo]; sc_p[mo] = sc_c[mo]; }
+        }
+        if constexpr (FIRST) __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2: one bidirectional GRU layer (rnn_class.py:142-148,165-171), both
+// directions in one grid (blockIdx.y).  A workgroup stages its direction's
+// packed weights in LDS once; each wave then owns tiles of 16 windows and runs
+// the 35-step recurrence with h, r*h and all pre-activations in registers.
+// LAST = true fuses the dense(128->1) partial dot (rnn_class.py:179) instead
+// of writing h.
+// ------------------------------------------------------------------------------------------
+template <int CIN, bool LAST>
+__global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restrict__ wpack,  // [2][gru_pack_floats(CIN)]
+                                                           const f32x4* __restrict__ X,      // [tile][t][CIN/16][lane]
+                                                           f32x4* __restrict__ Y,            // [tile][t][8][lane]
+                                                           float* __restrict__ P,            // [2][tile][t][16]
+                                                           int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KGX = CIN / 16;   // f32x4 registers of x per lane and step
+    constexpr int KSX = CIN / 4;    // k-steps of the x part
+    constexpr int PACK = gru_pack_floats(CIN);
+    constexpr int XN4 = gru_x_floats(CIN) / 4;        // region sizes in f32x4 units
+    constexpr int HG4 = gru_hg_floats() / 4;
+    constexpr int BIAS = gru_bias_off(CIN);
+    constexpr int DENSE = gru_dense_off(CIN);
+
+    const int dir = blockIdx.y;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < PACK / 4; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4;
+    const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;     // + (ks*3+g)*64
+    const f32x4* WG = WX + XN4;                                        // + (ks*2+g)*64
+    const f32x4* WC = WG + HG4;                                        // + ks*64
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;  // + mo*4
+    const f32x4* D4 = reinterpret_cast<const f32x4*>(lds + DENSE) + q; // + m*4
+
+    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+        f32x4 h[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // GRUCellZeroState
+        f32x4 xc[KGX];
+        {
+            const int t0 = dir ? (CF_T - 1) : 0;
+            const f32x4* src = X + ((int64_t)tile * CF_T + t0) * KGX * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+        }
+        for (int s = 0; s < CF_T; ++s) {
+            const int t = dir ? (CF_T - 1 - s) : s;    // bw = time-reversed sequence (ReverseV2)
+            f32x4 acc[12];
+#pragma unroll
+            for (int mo = 0; mo < 12; ++mo) acc[mo] = B4[mo * 4];
+            // The A fragments are software-pipelined one k-step ahead by hand; the
+            // sched_barriers keep hipcc from hoisting hundreds of ds_reads (it spills otherwise).
+            f32x4 ac[3], an[3];
+            ac[0] = WX[0]; ac[1] = WX[64]; ac[2] = WX[128];
+            // x part: [r | u | c] += Wx^T x_t
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                if (ks + 1 < KSX) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) an[g] = WX[((ks + 1) * 3 + g) * 64];
+                } else {
+                    an[0] = WG[0]; an[1] = WG[64];
+                }
+                const float b = xc[ks >> 2][ks & 3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    acc[4 * g + 0] = MFMA16(ac[g].x, b, acc[4 * g + 0]);
+                    acc[4 * g + 1] = MFMA16(ac[g].y, b, acc[4 * g + 1]);
+                    acc[4 * g + 2] = MFMA16(ac[g].z, b, acc[4 * g + 2]);
+                    acc[4 * g + 3] = MFMA16(ac[g].w, b, acc[4 * g + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ac[g] = an[g];
+            }
+            // x_t is dead: fetch the next step's x into the same registers (clamped on the last
+            // step: a harmless re-read); the h part below hides the latency.
+            {
+                int tn = dir ? (t - 1) : (t + 1);
+                tn = tn < 0 ? 0 : (tn > CF_T - 1 ? CF_T - 1 : tn);
+                const f32x4* src = X + ((int64_t)tile * CF_T + tn) * KGX * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+            }
+            // h part of the gates: [r | u] += Wh_g^T h          (gru_cell/MatMul)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + 1 < 16) {
+                    an[0] = WG[((ks + 1) * 2 + 0) * 64]; an[1] = WG[((ks + 1) * 2 + 1) * 64];
+                } else {
+                    an[0] = WC[0];
+                }
+                const float b = h[ks >> 2][ks & 3];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    acc[4 * g + 0] = MFMA16(ac[g].x, b, acc[4 * g + 0]);
+                    acc[4 * g + 1] = MFMA16(ac[g].y, b, acc[4 * g + 1]);
+                    acc[4 * g + 2] = MFMA16(ac[g].z, b, acc[4 * g + 2]);
+                    acc[4 * g + 3] = MFMA16(ac[g].w, b, acc[4 * g + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ac[0] = an[0]; ac[1] = an[1];
+            }
+            // r = sigmoid(.), r*h feeds the candidate matmul (reset applied BEFORE the matmul:
+            // gru_cell/mul -> concat_1 -> MatMul_1)
+            f32x4 rh[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rh[m][r] = cf_sigmoid(acc[m][r]) * h[m][r];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + 1 < 16) an[0] = WC[(ks + 1) * 64];
+                const float b = rh[ks >> 2][ks & 3];
+                acc[8] = MFMA16(ac[0].x, b, acc[8]);
+                acc[9] = MFMA16(ac[0].y, b, acc[9]);
+                acc[10] = MFMA16(ac[0].z, b, acc[10]);
+                acc[11] = MFMA16(ac[0].w, b, acc[11]);
+                __builtin_amdgcn_sched_barrier(0);
+                ac[0] = an[0];
+            }
+            // h' = u*h + (1-u)*c                                  (gru_cell/mul_1, sub, mul_2, add)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = cf_sigmoid(acc[4 + m][r]);
+                    const float c = cf_tanh(acc[8 + m][r]);
+                    h[m][r] = fmaf(u, h[m][r] - c, c);
+                }
+            }
+            if constexpr (!LAST) {
+                f32x4* dst = Y + (((int64_t)tile * CF_T + t) * 8 + dir * 4) * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dst[m * 64] = h[m];
+            } else {
+                // partial logit of this direction: sum_f w[f] * h[f]   (final_fully_connected/MatMul)
+                float p = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 wd = D4[m * 4];
+                    p = fmaf(wd.x, h[m].x, p); p = fmaf(wd.y, h[m].y, p);
+                    p = fmaf(wd.z, h[m].z, p); p = fmaf(wd.w, h[m].w, p);
+                }
+                p += __shfl_xor(p, 16);
+                p += __shfl_xor(p, 32);
+                if (lane < 16) P[(((int64_t)dir * n_tiles + tile) * CF_T + t) * 16 + lane] = p;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3: head -- logits = p_fw + p_bw + b, probs = sigmoid (rnn_class.py:84,179-181),
+// transposing the [tile][t][16] partials back to the reference's window-major order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, float bias, float* __restrict__ probs,
+                                                   int64_t n_windows, int n_tiles) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_windows * CF_T) return;
+    const int64_t w = idx / CF_T;
+    const int t = (int)(idx - w * CF_T);
+    const int64_t tile = w >> 4;
+    const int wl = (int)(w & 15);
+    const float z = P[((tile)*CF_T + t) * 16 + wl] + P[(((int64_t)n_tiles + tile) * CF_T + t) * 16 + wl] + bias;
+    probs[idx] = 1.0f / (1.0f + expf(-z));
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 4: class_from_threshold + correct_short (infer.py:128-138,174-198) per read.
+// A positive sample survives iff its positive run (inside its own read) has length >= min_run.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ probs,
+                                                          const int64_t* __restrict__ read_offsets, int64_t n_reads,
+                                                          float threshold, int min_run, uint8_t* __restrict__ labels) {
+    const int64_t total = read_offsets[n_reads];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    uint8_t out = 0;
+    if (probs[i] >= threshold) {
+        // read containing i: largest r with read_offsets[r] <= i
+        int64_t lo = 0, hi = n_reads;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (read_offsets[mid] <= i) lo = mid; else hi = mid;
+        }
+        const int64_t beg = read_offsets[lo], end = read_offsets[lo + 1];
+        int run = 1;
+        for (int64_t j = i - 1; j >= beg && run < min_run && probs[j] >= threshold; --j) ++run;
+        for (int64_t j = i + 1; j < end && run < min_run && probs[j] >= threshold; ++j) ++run;
+        out = run >= min_run ? 1 : 0;
+    }
+    labels[i] = out;
+}
+
+// ==========================================================================================
+// Host side
+// ==========================================================================================
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_UNUSED };
+static const char* k_slot_names[CF_PROF_SLOTS] = {"res_block_first", "res_block",      "gru_layer_first", "gru_layer_mid",
+                                                  "gru_layer_last",  "head",           "postprocess",     "unused"};
+
+struct cf_model {
+    cf_hparams hp;
+    int device = 0;
+    int n_cu = 256;
+    std::vector<float*> d_res;   // per residual block packed weights
+    std::vector<float*> d_gru;   // per layer packed weights [2 dirs]
+    std::vector<int> gru_cin;
+    float dense_bias = 0.f;
+    // workspace
+    int64_t cap_windows = 0;
+    int64_t cap_tiles = 0;
+    float* d_a[2] = {nullptr, nullptr};   // conv ping-pong, F = 32
+    float* d_y[2] = {nullptr, nullptr};   // GRU layer outputs ping-pong, F = 128
+    float* d_p = nullptr;                 // dense partials [2][tiles][35][16]
+    int64_t ws_bytes = 0;
+    int64_t last_windows = 0;             // windows of the last pass (debug hook)
+    // profiling
+    bool prof = false;
+    struct Ev { hipEvent_t a, b; int slot; };
+    std::vector<Ev> ev_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[CF_PROF_SLOTS] = {0};
+    int64_t prof_n[CF_PROF_SLOTS] = {0};
+};
+
+// ---- weight packing ----------------------------------------------------------------------
+static void pack_vec(float* dst, const std::vector<double>& v) {  // [mo][q][r] order == natural order of 16mo+4q+r
+    for (size_t i = 0; i < v.size(); ++i) dst[i] = (float)v[i];
+}
+
+// 32x32 unit: dst[(ks*64 + lane)*2 + mo] = W[in = frag_feature(ks, lane>>4)][out = 16mo + (lane&15)]
+static void pack_unit(float* dst, const std::vector<double>& w /*[32 in][32 out]*/) {
+    for (int ks = 0; ks < 8; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int mo = 0; mo < 2; ++mo)
+                dst[(ks * 64 + lane) * 2 + mo] = (float)w[frag_feature(ks, lane >> 4) * 32 + 16 * mo + (lane & 15)];
+}
+
+struct FoldedConv {
+    int k = 0, cin = 0;
+    std::vector<double> w;  // [k][cin][32] scaled by BN
+    std::vector<double> b;  // [32]
+};
+
+// y = BN(conv(x)) = conv'(x): W' = W*s, b' = b*s + beta - mean*s, s = gamma*rsqrt(var+eps)
+static FoldedConv fold(const cf_conv_bn& c, float eps) {
+    FoldedConv f;
+    f.k = c.ksize; f.cin = c.cin;
+    f.w.resize((size_t)c.ksize * c.cin * CF_C);
+    f.b.resize(CF_C);
+    for (int o = 0; o < CF_C; ++o) {
+        // same arithmetic as the unfused graph: inv = rsqrt(var + eps) * gamma (fp32 inputs, double math)
+        const double s = (double)c.gamma[o] / std::sqrt((double)c.moving_variance[o] + (double)eps);
+        f.b[o] = (double)c.bias[o] * s + (double)c.beta[o] - (double)c.moving_mean[o] * s;
+        for (int k = 0; k < c.ksize; ++k)
+            for (int i = 0; i < c.cin; ++i)
+                f.w[((size_t)k * c.cin + i) * CF_C + o] = (double)c.kernel[((size_t)k * c.cin + i) * CF_C + o] * s;
+    }
+    return f;
+}
+
+static std::vector<double> tap(const FoldedConv& f, int k) {
+    return std::vector<double>(f.w.begin() + (size_t)k * f.cin * CF_C, f.w.begin() + (size_t)(k + 1) * f.cin * CF_C);
+}
+
+static int pack_res_block(const cf_conv_bn* c4, bool first, float eps, std::vector<float>& out) {
+    out.assign(res_pack_floats(first), 0.f);
+    const FoldedConv sc = fold(c4[0], eps), f1 = fold(c4[1], eps), f3 = fold(c4[2], eps), fl = fold(c4[3], eps);
+    const int cin = first ? 1 : CF_C;
+    if (sc.k != 1 || f1.k != 1 || f3.k != 3 || fl.k != 1 || sc.cin != cin || f1.cin != cin || f3.cin != CF_C || fl.cin != CF_C)
+        return fail(CF_ERR_INVALID, "residual block geometry not supported (need k = 1,1,3,1 and 32 channels)");
+    float* vecs = out.data() + res_units(first) * 1024;
+    if (first) {
+        for (int k = 0; k < 3; ++k) pack_unit(out.data() + k * 1024, tap(f3, k));
+        pack_unit(out.data() + 3 * 1024, tap(fl, 0));
+        pack_vec(vecs + 0 * 32, f3.b); pack_vec(vecs + 1 * 32, fl.b);
+        pack_vec(vecs + 2 * 32, sc.w); pack_vec(vecs + 3 * 32, sc.b);
+        pack_vec(vecs + 4 * 32, f1.w); pack_vec(vecs + 5 * 32, f1.b);
+    } else {
+        pack_unit(out.data() + 0 * 1024, tap(sc, 0));
+        pack_unit(out.data() + 1 * 1024, tap(f1, 0));
+        for (int k = 0; k < 3; ++k) pack_unit(out.data() + (2 + k) * 1024, tap(f3, k));
+        pack_unit(out.data() + 5 * 1024, tap(fl, 0));
+        pack_vec(vecs + 0 * 32, sc.b); pack_vec(vecs + 1 * 32, f1.b);
+        pack_vec(vecs + 2 * 32, f3.b); pack_vec(vecs + 3 * 32, fl.b);
+    }
+    return CF_OK;
+}
+
+static void pack_gru_dir(const cf_gru_dir& g, int cin, const float* dense_w /*64 floats of this direction or null*/, float* out) {
+    auto wfull = [&](int in, int o) -> float {
+        return o < 2 * CF_H ? g.gates_kernel[(size_t)in * 2 * CF_H + o] : g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)];
+    };
+    float* px = out;
+    for (int ks = 0; ks < cin / 4; ++ks)
+        for (int gq = 0; gq < 3; ++gq)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    px[((ks * 3 + gq) * 64 + lane) * 4 + j] = wfull(frag_feature(ks, lane >> 4), 16 * (4 * gq + j) + (lane & 15));
+    float* pg = out + gru_x_floats(cin);
+    for (int ks = 0; ks < 16; ++ks)
+        for (int gq = 0; gq < 2; ++gq)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    pg[((ks * 2 + gq) * 64 + lane) * 4 + j] = wfull(cin + frag_feature(ks, lane >> 4), 16 * (4 * gq + j) + (lane & 15));
+    float* pc = pg + gru_hg_floats();
+    for (int ks = 0; ks < 16; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j)
+                pc[(ks * 64 + lane) * 4 + j] = wfull(cin + frag_feature(ks, lane >> 4), 2 * CF_H + 16 * j + (lane & 15));
+    float* pb = out + gru_bias_off(cin);
+    for (int i = 0; i < 2 * CF_H; ++i) pb[i] = g.gates_bias[i];
+    for (int i = 0; i < CF_H; ++i) pb[2 * CF_H + i] = g.candidate_bias[i];
+    float* pd = out + gru_dense_off(cin);
+    for (int i = 0; i < CF_H; ++i) pd[i] = dense_w ? dense_w[i] : 0.f;
+}
+
+// ---- model lifetime ----------------------------------------------------------------------
+static int upload(const std::vector<float>& host, float** dev) {
+    HIP_TRY(hipMalloc((void**)dev, host.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return CF_OK;
+}
+
+extern "C" void cf_model_destroy(cf_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (float* p : m->d_res) if (p) (void)hipFree(p);
+    for (float* p : m->d_gru) if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) { if (m->d_a[i]) (void)hipFree(m->d_a[i]); if (m->d_y[i]) (void)hipFree(m->d_y[i]); }
+    if (m->d_p) (void)hipFree(m->d_p);
+    for (auto& e : m->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : m->ev_pool) (void)hipEventDestroy(e);
+    delete m;
+}
+
+extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int device, cf_model** out) {
+    if (!w || !hp || !out) return fail(CF_ERR_INVALID, "cf_model_create: null argument");
+    *out = nullptr;
+    if (hp->window != CF_T) return fail(CF_ERR_INVALID, "window must be 35 (rnn_class.py:27)");
+    if (hp->layer_size != CF_H || hp->n_layers < 1)
+        return fail(CF_ERR_INVALID, "kernels are specialised for layer_size = 64, n_layers >= 1");
+    if (hp->n_layers_res < 1 || hp->layer_size_res != CF_C)
+        return fail(CF_ERR_INVALID, "kernels are specialised for layer_size_res = 32, n_layers_res >= 1 (ResNetRNN)");
+    if (!w->conv || !w->gru || !w->dense_kernel || !w->dense_bias) return fail(CF_ERR_INVALID, "cf_weights has null members");
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(CF_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    cf_model* m = new cf_model();
+    m->hp = *hp;
+    m->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
+    int rc = CF_OK;
+    // residual blocks
+    for (int b = 0; b < hp->n_layers_res && rc == CF_OK; ++b) {
+        std::vector<float> blob;
+        rc = pack_res_block(w->conv + 4 * b, b == 0, hp->bn_epsilon, blob);
+        if (rc == CF_OK) { float* d = nullptr; rc = upload(blob, &d); m->d_res.push_back(d); }
+    }
+    // GRU layers
+    for (int l = 0; l < hp->n_layers && rc == CF_OK; ++l) {
+        const int cin = l == 0 ? CF_C : 2 * CF_H;
+        if (w->gru[2 * l].cin != cin || w->gru[2 * l + 1].cin != cin) { rc = fail(CF_ERR_INVALID, "GRU layer input width mismatch"); break; }
+        const bool last = l == hp->n_layers - 1;
+        std::vector<float> blob((size_t)2 * gru_pack_floats(cin));
+        for (int d = 0; d < 2; ++d)
+            pack_gru_dir(w->gru[2 * l + d], cin, last ? w->dense_kernel + d * CF_H : nullptr, blob.data() + (size_t)d * gru_pack_floats(cin));
+        float* dptr = nullptr;
+        rc = upload(blob, &dptr);
+        m->d_gru.push_back(dptr);
+        m->gru_cin.push_back(cin);
+    }
+    m->dense_bias = w->dense_bias[0];
+    // workspace
+    if (rc == CF_OK) {
+        int64_t cap = hp->max_windows_per_pass > 0 ? hp->max_windows_per_pass : 32768;
+        cap = (cap + CF_TILE - 1) / CF_TILE * CF_TILE;
+        m->cap_windows = cap;
+        m->cap_tiles = cap / CF_TILE;
+        const size_t a_bytes = (size_t)m->cap_tiles * CF_T * 2 * 64 * sizeof(f32x4);
+        const size_t y_bytes = (size_t)m->cap_tiles * CF_T * 8 * 64 * sizeof(f32x4);
+        const size_t p_bytes = (size_t)2 * m->cap_tiles * CF_T * 16 * sizeof(float);
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&m->d_a[i], a_bytes);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&m->d_y[i], y_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->d_p, p_bytes);
+        if (e != hipSuccess) rc = fail(CF_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
+        m->ws_bytes = (int64_t)(2 * a_bytes + 2 * y_bytes + p_bytes);
+    }
+    if (rc == CF_OK) {
+        // opt in to > 64 KiB dynamic LDS for every GRU instantiation we may launch
+        hipError_t e = hipSuccess;
+        auto optin = [&](const void* f, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+        optin((const void*)gru_layer_kernel<32, false>, gru_pack_floats(32) * 4);
+        optin((const void*)gru_layer_kernel<32, true>, gru_pack_floats(32) * 4);
+        optin((const void*)gru_layer_kernel<128, false>, gru_pack_floats(128) * 4);
+        optin((const void*)gru_layer_kernel<128, true>, gru_pack_floats(128) * 4);
+        if (e != hipSuccess) rc = fail(CF_ERR_HIP, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
+    }
+    if (rc != CF_OK) { std::string keep = g_err; cf_model_destroy(m); g_err = keep; return rc; }
+    *out = m;
+    return CF_OK;
+}
+
+// ---- launch helpers ----------------------------------------------------------------------
+static int prof_begin(cf_model* m, int slot, hipStream_t s, size_t* idx) {
+    if (!m->prof) return CF_OK;
+    cf_model::Ev ev;
+    ev.slot = slot;
+    for (hipEvent_t* p : {&ev.a, &ev.b}) {
+        if (!m->ev_pool.empty()) { *p = m->ev_pool.back(); m->ev_pool.pop_back(); }
+        else HIP_TRY(hipEventCreate(p));
+    }
+    HIP_TRY(hipEventRecord(ev.a, s));
+    m->ev_pending.push_back(ev);
+    *idx = m->ev_pending.size() - 1;
+    return CF_OK;
+}
+static int prof_end(cf_model* m, hipStream_t s, size_t idx) {
+    if (!m->prof) return CF_OK;
+    HIP_TRY(hipEventRecord(m->ev_pending[idx].b, s));
+    return CF_OK;
+}
+
+template <int CIN, bool LAST>
+static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
+    const int groups = (n_tiles + 7) / 8;                       // one workgroup pass = 8 tiles (one per wave)
+    int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;            // persistent: half the CUs per direction
+    constexpr int lds_bytes = gru_pack_floats(CIN) * 4;
+    if (lds_bytes <= 80 * 1024) per_dir *= 2;                   // two workgroups fit per CU
+    const int gx = groups < per_dir ? groups : per_dir;
+    size_t pi = 0;
+    int rc = prof_begin(m, slot, s, &pi);
+    if (rc != CF_OK) return rc;
+    hipLaunchKernelGGL((gru_layer_kernel<CIN, LAST>), dim3(gx, 2), dim3(512), lds_bytes, s, wpack,
+                       reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles);
+    HIP_TRY(hipGetLastError());
+    return prof_end(m, s, pi);
+}
+
+static int run_pass(cf_model* m, const float* x, int64_t n_windows, float* probs, hipStream_t s) {
+    const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    int rc;
+    size_t pi = 0;
+    // residual blocks
+    const int res_grid = std::min((n_tiles + 3) / 4, m->n_cu * 4);
+    for (int b = 0; b < m->hp.n_layers_res; ++b) {
+        float* dst = m->d_a[b & 1];
+        if (b == 0) {
+            if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
+            const int lds_bytes = (res_pack_floats(true) + 4 * CF_TILE * CF_T) * 4;
+            hipLaunchKernelGGL((res_block_kernel<true>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[0], x,
+                               (const f32x4*)nullptr, reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
+        } else {
+            if ((rc = prof_begin(m, SLOT_RES, s, &pi)) != CF_OK) return rc;
+            const int lds_bytes = res_pack_floats(false) * 4;
+            hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
+                               reinterpret_cast<const f32x4*>(m->d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
+        }
+        HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+    }
+    const float* cur = m->d_a[(m->hp.n_layers_res - 1) & 1];
+    // GRU layers
+    for (int l = 0; l < m->hp.n_layers; ++l) {
+        const bool last = l == m->hp.n_layers - 1;
+        float* y = m->d_y[l & 1];
+        if (l == 0) {
+            rc = last ? launch_gru<32, true>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU_LAST)
+                      : launch_gru<32, false>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU0);
+        } else {
+            rc = last ? launch_gru<128, true>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU_LAST)
+                      : launch_gru<128, false>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU);
+        }
+        if (rc != CF_OK) return rc;
+        cur = y;
+    }
+    // head
+    if ((rc = prof_begin(m, SLOT_HEAD, s, &pi)) != CF_OK) return rc;
+    const int64_t total = n_windows * CF_T;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, m->d_p, m->dense_bias, probs, n_windows, n_tiles);
+    HIP_TRY(hipGetLastError());
+    if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+    m->last_windows = n_windows;
+    return CF_OK;
+}
+
+extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* probs, void* stream) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_infer: null model");
+    if (n_windows < 0) return fail(CF_ERR_INVALID, "cf_infer: negative n_windows");
+    if (n_windows == 0) return CF_OK;
+    if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer: null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int64_t off = 0; off < n_windows; off += m->cap_windows) {
+        const int64_t n = std::min(m->cap_windows, n_windows - off);
+        const int rc = run_pass(m, x + off * CF_T, n, probs + off * CF_T, s);
+        if (rc != CF_OK) return rc;
+    }
+    return CF_OK;
+}
+
+extern "C" int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, float* probs) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_infer_host: null model");
+    if (n_windows < 0) return fail(CF_ERR_INVALID, "cf_infer_host: negative n_windows");
+    if (n_windows == 0) return CF_OK;
+    if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer_host: null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t bytes = (size_t)n_windows * CF_T * sizeof(float);
+    float *dx = nullptr, *dp = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, bytes));
+    hipError_t e = hipMalloc((void**)&dp, bytes);
+    if (e != hipSuccess) { (void)hipFree(dx); return fail(CF_ERR_NOMEM, "cf_infer_host: hipMalloc failed"); }
+    int rc = CF_OK;
+    if ((e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
+    if (rc == CF_OK) rc = cf_infer(m, dx, n_windows, dp, nullptr);
+    if (rc == CF_OK && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
+    if (rc == CF_OK && (e = hipMemcpy(probs, dp, bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
+    (void)hipFree(dx);
+    (void)hipFree(dp);
+    return rc;
+}
+
+extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets, int64_t n_reads, float threshold,
+                              int32_t min_run, uint8_t* labels, void* stream) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_postprocess: null model");
+    if (n_reads < 0) return fail(CF_ERR_INVALID, "cf_postprocess: negative n_reads");
+    if (n_reads == 0) return CF_OK;
+    if (!probs || !read_offsets || !labels) return fail(CF_ERR_INVALID, "cf_postprocess: null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, read_offsets + n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (total <= 0) return CF_OK;
+    size_t pi = 0;
+    int rc = prof_begin(m, SLOT_POST, s, &pi);
+    if (rc != CF_OK) return rc;
+    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probs, read_offsets, n_reads,
+                       threshold, (int)min_run, labels);
+    HIP_TRY(hipGetLastError());
+    return prof_end(m, s, pi);
+}
+
+// ---- profiling ---------------------------------------------------------------------------
+static int prof_collect(cf_model* m) {
+    for (auto& ev : m->ev_pending) {
+        HIP_TRY(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        m->prof_ms[ev.slot] += ms;
+        m->prof_n[ev.slot] += 1;
+        m->ev_pool.push_back(ev.a);
+        m->ev_pool.push_back(ev.b);
+    }
+    m->ev_pending.clear();
+    return CF_OK;
+}
+extern "C" int cf_profile_enable(cf_model* m, int on) {
+    if (!m) return fail(CF_ERR_INVALID, "null model");
+    if (!on && m->prof) { int rc = prof_collect(m); if (rc != CF_OK) return rc; }
+    m->prof = on != 0;
+    return CF_OK;
+}
+extern "C" int cf_profile_reset(cf_model* m) {
+    if (!m) return fail(CF_ERR_INVALID, "null model");
+    int rc = prof_collect(m);
+    if (rc != CF_OK) return rc;
+    for (int i = 0; i < CF_PROF_SLOTS; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; }
+    return CF_OK;
+}
+extern "C" int cf_profile_read(cf_model* m, double ms[CF_PROF_SLOTS], int64_t launches[CF_PROF_SLOTS]) {
+    if (!m || !ms || !launches) return fail(CF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = prof_collect(m);
+    if (rc != CF_OK) return rc;
+    for (int i = 0; i < CF_PROF_SLOTS; ++i) { ms[i] = m->prof_ms[i]; launches[i] = m->prof_n[i]; }
+    return CF_OK;
+}
+extern "C" const char* cf_profile_slot_name(int slot) {
+    return (slot >= 0 && slot < CF_PROF_SLOTS) ? k_slot_names[slot] : "";
+}
+
+// ---- debug hook --------------------------------------------------------------------------
+extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host) {
+    if (!m || !out_host) return fail(CF_ERR_INVALID, "cf_debug_stage: null argument");
+    if (n_windows <= 0 || n_windows > m->last_windows) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds the last pass");
+    HIP_TRY(hipSetDevice(m->device));
+    int feats, mt;
+    const float* src;
+    if (stage >= 0 && stage < m->hp.n_layers_res) {
+        // ping-pong: only the last two blocks survive a pass
+        if (stage < m->hp.n_layers_res - 2) return fail(CF_ERR_INVALID, "cf_debug_stage: stage overwritten");
+        feats = CF_C; mt = 2; src = m->d_a[stage & 1];
+    } else if (stage >= m->hp.n_layers_res && stage < m->hp.n_layers_res + m->hp.n_layers - 1) {
+        const int l = stage - m->hp.n_layers_res;
+        if (l < m->hp.n_layers - 3) return fail(CF_ERR_INVALID, "cf_debug_stage: stage overwritten");
+        feats = 2 * CF_H; mt = 8; src = m->d_y[l & 1];
+    } else {
+        return fail(CF_ERR_INVALID, "cf_debug_stage: no such stage");
+    }
+    const int64_t n_tiles = (n_windows + CF_TILE - 1) / CF_TILE;
+    std::vector<float> frag((size_t)n_tiles * CF_T * mt * 256);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(frag.data(), src, frag.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t w = 0; w < n_windows; ++w)
+        for (int t = 0; t < CF_T; ++t)
+            for (int f = 0; f < feats; ++f) {
+                const int mo = f >> 4, qq = (f >> 2) & 3, r = f & 3;
+                const int lane = qq * 16 + (int)(w & 15);
+                out_host[(w * CF_T + t) * feats + f] = frag[((((w >> 4) * CF_T + t) * mt + mo) * 64 + lane) * 4 + r];
+            }
+    return CF_OK;
+}
+
+extern "C" int64_t cf_workspace_bytes(const cf_model* m) { return m ? m->ws_bytes : 0; }
+extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
+extern "C" const char* cf_version(void) { return "catfish_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }

@@ -1,0 +1,127 @@
+"""Thin host layer over the C ABI: owns one cf_model on one MI355X.
+
+PyTorch is used only as plumbing (device buffers, the current HIP stream);
+numpy callers go through ``cf_infer_host`` and need no torch at all.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+WINDOW = N.CF_WINDOW
+DEFAULT_MAX_WINDOWS = 32768   # one pass covers 256 reads of 4096 samples (30 208 windows)
+
+
+class HipEngine(object):
+    """The forward pass of one ResNetRNN checkpoint on one GPU."""
+
+    def __init__(self, weights, layer_size=64, n_layers=3, layer_size_res=32, n_layers_res=2,
+                 device=0, max_windows_per_pass=DEFAULT_MAX_WINDOWS, bn_epsilon=1e-3):
+        self._lib = N.lib()
+        self._handle = C.c_void_p()
+        hp = N.cf_hparams(int(layer_size), int(n_layers), int(layer_size_res), int(n_layers_res),
+                          WINDOW, float(bn_epsilon), int(max_windows_per_pass))
+        w, keep = N.build_weight_structs(weights, int(n_layers), int(n_layers_res))
+        N.check(self._lib.cf_model_create(C.byref(w), C.byref(hp), int(device), C.byref(self._handle)))
+        del keep  # the library copied/re-tiled everything
+        self.device = int(device)
+        self.n_layers = int(n_layers)
+        self.n_layers_res = int(n_layers_res)
+        self.layer_size = int(layer_size)
+        self.layer_size_res = int(layer_size_res)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.cf_model_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self._lib.cf_workspace_bytes(self._handle))
+
+    # ------------------------------------------------------------------ inference
+    @staticmethod
+    def _check_windows(shape):
+        if len(shape) == 3 and shape[2] == 1:
+            shape = shape[:2]
+        if len(shape) != 2 or shape[1] != WINDOW:
+            raise ValueError("input must be [n_windows, %d(, 1)], got %s" % (WINDOW, tuple(shape)))
+        return int(shape[0])
+
+    def infer_host(self, x):
+        """numpy [N,35(,1)] any float dtype -> numpy float32 [N*35] (H2D/D2H inside)."""
+        x = np.asarray(x)
+        n = self._check_windows(x.shape)
+        x32 = np.ascontiguousarray(x.reshape(n, WINDOW), dtype=np.float32)
+        out = np.empty(n * WINDOW, dtype=np.float32)
+        N.check(self._lib.cf_infer_host(self._handle, x32.ctypes.data_as(C.c_void_p), n,
+                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def infer_device(self, x, out=None, stream=None):
+        """torch CUDA float32 tensor [N,35(,1)] -> torch CUDA float32 [N*35], async on the stream."""
+        import torch
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise ValueError("infer_device needs a float32 CUDA tensor")
+        if x.device.index != self.device:
+            raise ValueError("tensor lives on cuda:%s, model on cuda:%d" % (x.device.index, self.device))
+        n = self._check_windows(tuple(x.shape))
+        x = x.contiguous()
+        if out is None:
+            out = torch.empty(n * WINDOW, dtype=torch.float32, device=x.device)
+        elif out.numel() != n * WINDOW or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 tensor of %d elements" % (n * WINDOW))
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device)
+        N.check(self._lib.cf_infer(self._handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                   C.c_void_p(stream.cuda_stream)))
+        return out
+
+    def postprocess_device(self, probs, read_offsets, threshold=0.5, min_run=15, out=None, stream=None):
+        """Device threshold + correct_short: float32 probs, int64 read_offsets[n_reads+1] -> uint8 labels."""
+        import torch
+        if not probs.is_cuda or probs.dtype != torch.float32 or not probs.is_contiguous():
+            raise ValueError("probs must be a contiguous float32 CUDA tensor")
+        if read_offsets.dtype != torch.int64 or not read_offsets.is_cuda:
+            raise ValueError("read_offsets must be an int64 CUDA tensor")
+        n_reads = int(read_offsets.numel()) - 1
+        if out is None:
+            out = torch.empty(probs.numel(), dtype=torch.uint8, device=probs.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(probs.device)
+        N.check(self._lib.cf_postprocess(self._handle, C.c_void_p(probs.data_ptr()),
+                                         C.c_void_p(read_offsets.data_ptr()), n_reads, float(threshold),
+                                         int(min_run), C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(stream.cuda_stream)))
+        return out
+
+    # ------------------------------------------------------------------ profiling / debug
+    def profile_enable(self, on=True):
+        N.check(self._lib.cf_profile_enable(self._handle, 1 if on else 0))
+
+    def profile_reset(self):
+        N.check(self._lib.cf_profile_reset(self._handle))
+
+    def profile_read(self):
+        """-> {kernel slot name: (total ms, launches)} since the last reset."""
+        ms = (C.c_double * N.CF_PROF_SLOTS)()
+        cnt = (C.c_int64 * N.CF_PROF_SLOTS)()
+        N.check(self._lib.cf_profile_read(self._handle, ms, cnt))
+        return {self._lib.cf_profile_slot_name(i).decode(): (float(ms[i]), int(cnt[i]))
+                for i in range(N.CF_PROF_SLOTS) if cnt[i]}
+
+    def debug_stage(self, stage, n_windows):
+        feats = self.layer_size_res if stage < self.n_layers_res else 2 * self.layer_size
+        out = np.empty((n_windows, WINDOW, feats), dtype=np.float32)
+        N.check(self._lib.cf_debug_stage(self._handle, int(stage), int(n_windows), out.ctypes.data_as(C.c_void_p)))
+        return out

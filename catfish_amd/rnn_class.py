@@ -1,0 +1,180 @@
+"""RNN -- the reference's model object (catfish/models/rnn_class.py:9-270) backed by the HIP engine.
+
+Same constructor keywords, attributes and methods as the reference class; the
+TensorFlow graph + ``tf.Session`` are replaced by one ``cf_model`` on one
+MI355X (include/catfish_hip.h).  There is no CPU fallback: constructing the
+engine without the built HIP library raises.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import checkpoint
+from . import metrics
+from .engine import HipEngine, DEFAULT_MAX_WINDOWS
+
+
+class RNN(object):
+    def __init__(self, save=False, **kwargs):
+        # adjustable parameters (rnn_class.py:13-19)
+        self.batch_size = kwargs["batch_size"]
+        self.optimizer_choice = kwargs["optimizer_choice"]
+        self.learning_rate = kwargs["learning_rate"]
+        self.layer_size = kwargs["layer_size"]
+        self.n_layers = kwargs["n_layers"]
+        self.keep_prob = kwargs["keep_prob"]
+        self.keep_prob_test = 1.0
+
+        # set parameters (rnn_class.py:25-32)
+        self.n_inputs = 1
+        self.n_outputs = 1
+        self.window = 35
+        self.layer_sizes = [self.layer_size, ] * self.n_layers
+        self.saving_step = 10000
+        self.cell_type = "GRU"
+        if not hasattr(self, "_model_type"):
+            self._model_type = "bi" + self.cell_type + "-RNN"
+
+        # the reference validates the optimizer while building the graph (rnn_class.py:62-71)
+        if self.optimizer_choice not in ("Adam", "RMSProp"):
+            raise ValueError("Given optimizer choice is not known. Choose 'Adam' or 'RMSProp'.")
+
+        # MI355X-specific knobs (not in the reference)
+        self.device = int(kwargs.get("device", 0))
+        self.max_windows_per_pass = int(kwargs.get("max_windows_per_pass", DEFAULT_MAX_WINDOWS))
+
+        self.weights = None
+        self.engine = None
+        if save:
+            raise NotImplementedError("save=True (TensorBoard/model directory bookkeeping, rnn_class.py:43-46) "
+                                      "belongs to the training stack, which is out of scope of this path")
+
+        # saving test performance (rnn_class.py:51-54)
+        self.tp = 0
+        self.fp = 0
+        self.tn = 0
+        self.fn = 0
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def model_type(self):
+        return self._model_type
+
+    @property
+    def n_layers_res_(self):
+        return 0
+
+    @property
+    def layer_size_res_(self):
+        return 32
+
+    # ------------------------------------------------------------------ weights
+    def _load_engine(self, weights):
+        if self.engine is not None:
+            self.engine.close()
+        self.weights = weights
+        self.engine = HipEngine(weights, layer_size=self.layer_size, n_layers=self.n_layers,
+                                layer_size_res=self.layer_size_res_, n_layers_res=self.n_layers_res_,
+                                device=self.device, max_windows_per_pass=self.max_windows_per_pass)
+
+    def _initial_weights(self, seed=None):
+        """TF default initialisers: glorot-uniform kernels, zero biases,
+        GRU gates/bias = 1, gamma = 1, beta = 0, moving stats 0/1."""
+        rng = np.random.default_rng(seed)
+        w = {}
+
+        def glorot(shape, fan_in, fan_out):
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+        c = self.layer_size_res_
+        cin = 1
+        for j in range(4 * self.n_layers_res_):
+            k = 3 if j % 4 == 2 else 1
+            c_in = cin if j % 4 in (0, 1) else c
+            name = "conv1d" if j == 0 else "conv1d_%d" % j
+            bn = "batch_normalization" if j == 0 else "batch_normalization_%d" % j
+            w[name + "/kernel"] = glorot((k, c_in, c), k * c_in, k * c)
+            w[name + "/bias"] = np.zeros(c, np.float32)
+            w[bn + "/gamma"] = np.ones(c, np.float32)
+            w[bn + "/beta"] = np.zeros(c, np.float32)
+            w[bn + "/moving_mean"] = np.zeros(c, np.float32)
+            w[bn + "/moving_variance"] = np.ones(c, np.float32)
+            if j % 4 == 3:
+                cin = c
+        c_in = c if self.n_layers_res_ > 0 else 1
+        h = self.layer_size
+        for layer in range(self.n_layers):
+            for d in ("fw", "bw"):
+                p = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell" % (layer, d)
+                w[p + "/gates/kernel"] = glorot((c_in + h, 2 * h), c_in + h, 2 * h)
+                w[p + "/gates/bias"] = np.ones(2 * h, np.float32)
+                w[p + "/candidate/kernel"] = glorot((c_in + h, h), c_in + h, h)
+                w[p + "/candidate/bias"] = np.zeros(h, np.float32)
+            c_in = 2 * h
+        w["final_fully_connected/kernel"] = glorot((2 * h, 1), 2 * h, 1)
+        w["final_fully_connected/bias"] = np.zeros(1, np.float32)
+        return w
+
+    def initialize_network(self, seed=None):
+        """rnn_class.py:186-188: fresh variables (random init instead of a checkpoint)."""
+        self._load_engine(self._initial_weights(seed))
+        print("\nNot yet initialized: ", [], "\n")
+
+    def restore_network(self, path, ckpnt="latest", meta=None):
+        """rnn_class.py:191-198: load checkpoint ``path/ckpnt`` (or the latest one in ``path``)."""
+        weights = checkpoint.read_inference_weights(path, ckpnt)
+        self._load_engine(weights)
+        parts = path.split("/")
+        print("Model {} restored\n".format(parts[-2] if len(parts) >= 2 else path))
+
+    def set_weights(self, weights):
+        """Load weights from a {TF variable name: array} dict (e.g. an exported .npz)."""
+        self._load_engine(dict(weights))
+
+    # ------------------------------------------------------------------ inference
+    def _require_engine(self):
+        if self.engine is None:
+            raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
+
+    def infer(self, input_x):
+        """rnn_class.py:213-219: [N,35,1] -> float64 confidences, flattened [N*35]."""
+        self._require_engine()
+        try:
+            import torch
+            is_tensor = isinstance(input_x, torch.Tensor)
+        except ImportError:
+            is_tensor = False
+        if is_tensor and input_x.is_cuda:
+            out = self.engine.infer_device(input_x.to(dtype=torch.float32))
+            return out.cpu().numpy().astype(float)
+        confidences = self.engine.infer_host(np.asarray(input_x))
+        return np.reshape(confidences, (-1)).astype(float)
+
+    def test_network(self, test_x, test_y, read_name, file_path, padding_size, threshold=0.5):
+        """rnn_class.py:222-261: predictions + accuracy/loss + running confusion counters."""
+        self._require_engine()
+        confidences = self.infer(test_x)
+        pred_vals = (confidences >= threshold).astype(np.int64)
+        test_labels = np.asarray(test_y).reshape(-1)
+        # accuracy: tf.equal(tf.round(p), y) (rnn_class.py:85-86); loss: mean sigmoid cross-entropy (:76-77)
+        test_acc = float(np.mean(np.round(confidences) == test_labels))
+        eps = np.finfo(np.float64).tiny
+        p = np.clip(confidences, eps, 1.0)
+        q = np.clip(1.0 - confidences, eps, 1.0)
+        test_loss = float(np.mean(-(test_labels * np.log(p) + (1.0 - test_labels) * np.log(q))))
+        true_pos, false_pos, true_neg, false_neg = metrics.confusion_matrix(test_labels, pred_vals)
+        self.tp += true_pos
+        self.fp += false_pos
+        self.tn += true_neg - padding_size
+        self.fn += false_neg
+        return test_acc, test_loss
+
+    def train_network(self, train_x, train_y, step):
+        raise NotImplementedError("training (rnn_class.py:201-210) is a 'next' row of the scope table; "
+                                  "this build implements the inference path")
+
+    def save_info(self):
+        raise NotImplementedError("save_info (rnn_class.py:264-270) belongs to the training stack")

@@ -1,0 +1,135 @@
+/*
+ * catfish_hip.h -- C ABI of the MI355X-native homopolymer-calling forward pass.
+ *
+ * This is the drop-in boundary for ONE call of the reference:
+ *
+ *     confidences = self.sess.run(self.predictions,
+ *                                 feed_dict={self.x: input_x, self.p_dropout: 1.0})
+ *                                         (reference catfish/models/rnn_class.py:214-216)
+ *
+ * i.e. the whole TensorFlow graph built by ResNetRNN.network_layer
+ * (catfish/models/resnet_class.py:17-25,44-82), RNN.network_layer
+ * (catfish/models/rnn_class.py:165-175), RNN.output_layer (:178-183) and
+ * RNN.compute_accuracy (:82-88, self.predictions = sigmoid(logits)).
+ * The reference has no native code; the entry points below are what a cgo /
+ * ctypes / N-API binding of that one call binds.  Plain pointers and sizes
+ * only -- no torch / TensorFlow types.
+ *
+ * Threading: one cf_model per device per host thread; cf_infer is
+ * asynchronous on the given HIP stream and keeps no global state.
+ * Errors: 0 = ok, negative = failure; cf_last_error() returns the message of
+ * the calling thread's last failure.
+ */
+#ifndef CATFISH_HIP_H
+#define CATFISH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_OK 0
+#define CF_ERR_INVALID -1     /* bad argument / unsupported geometry (Python raises ValueError) */
+#define CF_ERR_HIP -2         /* a HIP runtime call failed */
+#define CF_ERR_NOMEM -3
+
+#define CF_WINDOW 35          /* rnn_class.py:27 (self.window) */
+
+/* Hyper-parameters: the keys of ResNetRNN.txt parsed by
+ * neural_network.retrieve_hyperparams (catfish/neural_network.py:37-67)
+ * that shape the forward graph. */
+typedef struct cf_hparams {
+    int32_t layer_size;          /* GRU units per direction (rnn_class.py:16)        */
+    int32_t n_layers;            /* stacked bidirectional layers (rnn_class.py:17)   */
+    int32_t layer_size_res;      /* conv channels (resnet_class.py:11)               */
+    int32_t n_layers_res;        /* residual blocks (resnet_class.py:10); 0 = RNN    */
+    int32_t window;              /* must be 35                                       */
+    float bn_epsilon;            /* tf.layers.batch_normalization epsilon (1e-3)     */
+    int64_t max_windows_per_pass;/* workspace capacity; longer inputs are chunked    */
+} cf_hparams;
+
+/* One conv1d + batch_normalization pair, TF layout
+ * (resnet_class.py:60-61 / 64-65 / 69-70 / 74-75). */
+typedef struct cf_conv_bn {
+    const float* kernel;          /* [ksize, cin, layer_size_res] */
+    const float* bias;            /* [layer_size_res] */
+    const float* gamma;           /* [layer_size_res] */
+    const float* beta;
+    const float* moving_mean;
+    const float* moving_variance;
+    int32_t ksize;
+    int32_t cin;
+} cf_conv_bn;
+
+/* tf.contrib.rnn.GRUCell variables of one direction of one layer
+ * (rnn_class.py:146); kernel rows [0,cin) multiply x, rows [cin,cin+H) multiply h. */
+typedef struct cf_gru_dir {
+    const float* gates_kernel;     /* [cin + H, 2H]  columns [0,H) = r, [H,2H) = u */
+    const float* gates_bias;       /* [2H] */
+    const float* candidate_kernel; /* [cin + H, H] */
+    const float* candidate_bias;   /* [H] */
+    int32_t cin;
+} cf_gru_dir;
+
+/* All 74 inference tensors of the checkpoint, host pointers, TF layout. */
+typedef struct cf_weights {
+    const cf_conv_bn* conv;        /* 4 * n_layers_res entries, graph order:
+                                      per block: shortcut, first, middle (k=3), last */
+    const cf_gru_dir* gru;         /* 2 * n_layers entries: [layer][fw, bw] */
+    const float* dense_kernel;     /* final_fully_connected/kernel [2H, 1] (rnn_class.py:179) */
+    const float* dense_bias;       /* [1] */
+} cf_weights;
+
+typedef struct cf_model cf_model;
+
+/* Replaces neural_network.load_network + RNN.restore_network
+ * (catfish/neural_network.py:26-34, rnn_class.py:191-198): folds BN into the
+ * convs, re-tiles every matrix into MFMA A-fragment order and uploads it. */
+int cf_model_create(const cf_weights* w, const cf_hparams* hp, int device, cf_model** out);
+void cf_model_destroy(cf_model* m);
+
+/* Replaces RNN.infer's sess.run (rnn_class.py:213-219).
+ * x: device pointer, [n_windows, 35] fp32 (window-major, as reshape_input
+ * produces, catfish/infer.py:108-124).  probs: device pointer,
+ * [n_windows * 35] fp32 = sigmoid(logits), same order as the reference's
+ * flattened output.  stream: hipStream_t (NULL = default stream). */
+int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* probs, void* stream);
+
+/* Same with host buffers (synchronous; H2D / D2H included). */
+int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, float* probs);
+
+/* Read-level post-processing on device, replacing class_from_threshold +
+ * correct_short (catfish/infer.py:128-138,174-198): labels[i] = 1 iff
+ * probs[i] >= threshold and i lies in a positive run of length >= min_run
+ * inside its read.  Reads are given by read_offsets[n_reads + 1] (sample
+ * offsets into probs, device pointer, int64).  labels: device uint8. */
+int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets,
+                   int64_t n_reads, float threshold, int32_t min_run,
+                   uint8_t* labels, void* stream);
+
+/* Per-kernel device timing (HIP events on the launch stream) for bench.py's
+ * roofline report.  cf_profile_enable(m, 1) makes every cf_infer record
+ * events around each kernel; cf_profile_read synchronises and returns, for
+ * kernel slot k, the accumulated milliseconds and launch count since the
+ * last cf_profile_reset. */
+#define CF_PROF_SLOTS 8
+int cf_profile_enable(cf_model* m, int on);
+int cf_profile_reset(cf_model* m);
+int cf_profile_read(cf_model* m, double ms[CF_PROF_SLOTS], int64_t launches[CF_PROF_SLOTS]);
+const char* cf_profile_slot_name(int slot);
+
+/* Debug/test hook: copy an intermediate activation of the LAST pass to the
+ * host in natural [n_windows, 35, features] order.  stage: 0..n_layers_res-1
+ * = residual block outputs, n_layers_res + l = GRU layer l output (not
+ * available for the last layer, whose output only exists as logits). */
+int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host);
+
+int64_t cf_workspace_bytes(const cf_model* m);
+const char* cf_last_error(void);
+const char* cf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATFISH_HIP_H */

@@ -1,0 +1,74 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance: per-sample sigmoid outputs within 1e-4 of the fp64 oracle
+(BASELINE.json north_star); in practice fp32 MFMA lands ~1e-6.
+"""
+import numpy as np
+import pytest
+
+from oracle import catfish_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def engine(ckpt_weights):
+    from catfish_amd.engine import HipEngine
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096)
+    yield eng
+    eng.close()
+
+
+def test_golden_read_stages(engine, golden_read):
+    """Stage-by-stage parity on the first tile of the golden read (real checkpoint)."""
+    x = golden_read["x"]
+    probs = engine.infer_host(x)
+    for stage, key in ((0, "res0_w16"), (1, "res1_w16"), (2, "gru0_w16"), (3, "gru1_w16")):
+        got = engine.debug_stage(stage, 16)
+        err = np.abs(got - golden_read[key]).max()
+        assert err < 2e-5, "stage %s max err %g" % (key, err)
+    err = np.abs(probs.astype(np.float64) - golden_read["probs_fp64"]).max()
+    assert err < TOL, err
+
+
+def test_golden_read_probs(engine, golden_read):
+    probs = engine.infer_host(golden_read["x"])
+    assert probs.shape == (118 * 35,)
+    err = np.abs(probs.astype(np.float64) - golden_read["probs_fp64"]).max()
+    assert err < TOL, err
+    # label match rate vs the fp32 oracle
+    assert np.mean((probs >= 0.5) == (golden_read["probs_fp32"] >= 0.5)) == 1.0
+
+
+@pytest.mark.parametrize("n_windows", [1, 15, 16, 17, 127, 128, 129, 1000])
+def test_ragged_window_counts_random_weights(n_windows):
+    """Random weights (non-trivial BN stats/biases) and ragged tile/workgroup tails."""
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=n_windows)
+    rng = np.random.default_rng(n_windows)
+    x = rng.normal(0, 1.5, size=(n_windows, 35)).astype(np.float32)
+    eng = HipEngine(w, device=0, max_windows_per_pass=512)   # 1000 windows -> two passes
+    try:
+        got = eng.infer_host(x)
+    finally:
+        eng.close()
+    want = oracle.forward(x, w, np.float64)
+    err = np.abs(got - want).max()
+    assert err < TOL, err
+
+
+def test_device_path_matches_host_path(engine, golden_read):
+    torch = pytest.importorskip("torch")
+    x = torch.from_numpy(golden_read["x"]).cuda()
+    out = engine.infer_device(x)
+    torch.cuda.synchronize()
+    host = engine.infer_host(golden_read["x"])
+    assert np.array_equal(out.cpu().numpy(), host)
+
+
+def test_empty_and_bad_shapes(engine):
+    assert engine.infer_host(np.zeros((0, 35), np.float32)).shape == (0,)
+    with pytest.raises(ValueError):
+        engine.infer_host(np.zeros((4, 34), np.float32))
