@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- signal samples/s of the homopolymer-calling forward pass on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
+rank 0.  For N > 1 it is launched under ``torch.distributed.run`` (one rank per GPU).
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "config 2"): synthetic 4096-sample reads
+(seeded DAC squiggles, median/MAD normalised exactly like catfish/infer.py:96-105), cut into
+118 windows of 35 samples each (pad 34), 256 reads = 30 208 windows per step, fp32, weights of
+the reference's bundled checkpoint ckpnt-30000.  A step = device-resident normalised windows
+-> device-resident per-sample probabilities through the C ABI (cf_infer).  Reads shard across
+ranks with no collective on the data path (weak scaling: every rank runs K steps of its own reads).
+
+``value`` counts UN-PADDED signal samples (256 x 4096 per step and rank).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READ_LEN = 4096
+READS_PER_STEP = 256
+WINDOW = 35
+FLOP_PER_SAMPLE = 389504            # SURVEY.md 8d / BASELINE.md 2 (2 x 194 752 MAC)
+FLOP_PER_SAMPLE_GRU128 = 2 * 2 * (128 + 64) * 192   # one CIN=128 biGRU layer: 2 dirs x 2 FLOP x 192x192 MAC
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def make_reads(n_reads, seed):
+    """Seeded synthetic reads -> normalised float32 windows [n_reads, 118, 35]."""
+    rng = np.random.default_rng(seed)
+    n_ev = READ_LEN // 4 + 8
+    out = np.zeros((n_reads, 118 * WINDOW), dtype=np.float32)
+    for i in range(n_reads):
+        dwell = rng.geometric(1.0 / 9.0, size=n_ev)
+        while dwell.sum() < READ_LEN:
+            dwell = np.concatenate([dwell, rng.geometric(1.0 / 9.0, size=n_ev)])
+        levels = rng.normal(500.0, 60.0, size=len(dwell))
+        sig = np.repeat(levels, dwell)[:READ_LEN] + rng.normal(0.0, 8.0, size=READ_LEN)
+        dac = np.clip(np.rint(sig), 0, 2047).astype(np.int16)
+        shift = np.median(dac)                       # infer.py:100-105
+        scale = np.median(np.abs(dac - shift))
+        out[i, :READ_LEN] = ((dac - shift) / scale).astype(np.float32)
+    return out.reshape(n_reads, 118, WINDOW)
+
+
+def load_weights():
+    path = os.path.join(ROOT, "tests", "golden", "ckpnt-30000-inference.npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def cpu_baseline():
+    """CPU oracle timed on the host cores (oracle/cpu_baseline.py); runs BEFORE the GPU is initialised
+    because it spawns worker processes."""
+    from oracle import cpu_baseline as cb
+    return cb.run(os.path.join(ROOT, "tests", "golden", "ckpnt-30000-inference.npz"), read_len=READ_LEN)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pool-reads", type=int, default=2048, help="distinct synthetic reads per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="disable per-kernel HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_res = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from catfish_amd.engine import HipEngine
+    weights = load_weights()
+    eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118)
+
+    # every rank owns its own shard of reads (seeded by rank): no data-path collective
+    n_pool = max(READS_PER_STEP, (args.pool_reads // READS_PER_STEP) * READS_PER_STEP)
+    reads = make_reads(n_pool, seed=1000 + rank)
+    n_batches = n_pool // READS_PER_STEP
+    dev = torch.device("cuda", local_rank)
+    batches = [torch.from_numpy(reads[b * READS_PER_STEP:(b + 1) * READS_PER_STEP].reshape(-1, WINDOW)).to(dev)
+               for b in range(n_batches)]
+    outs = [torch.empty(READS_PER_STEP * 118 * WINDOW, dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        eng.infer_device(batches[i % n_batches], out=outs[i & 1])
+    torch.cuda.synchronize()
+
+    if not args.no_kernel_events:
+        eng.profile_enable(True)
+        eng.profile_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.infer_device(batches[i % n_batches], out=outs[i & 1])
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = eng.profile_read() if not args.no_kernel_events else {}
+    eng.profile_enable(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    samples_per_step = READS_PER_STEP * READ_LEN          # un-padded, per rank
+    value = world * args.steps * samples_per_step / dt
+
+    result = None
+    if rank == 0:
+        # parity spot-check of the benchmarked configuration against the oracle (not timed)
+        from oracle import catfish_oracle as oracle
+        chk = reads[:2]     # the launch keeps the benchmark's size (rocprof averages stay comparable)
+        got = eng.infer_device(batches[0], out=outs[0]).cpu().numpy()[:2 * 118 * WINDOW].astype(np.float64)
+        want64 = oracle.forward(chk.reshape(-1, WINDOW), weights, np.float64)
+        want32 = oracle.forward(chk.reshape(-1, WINDOW), weights, np.float32)
+        max_dp = float(np.abs(got - want64).max())
+        match = float(np.mean((got >= 0.5) == (want32 >= 0.5)))
+
+        roof = None
+        if "gru_layer_mid" in kern:
+            ms, n = kern["gru_layer_mid"]
+            avg_s = ms / n * 1e-3
+            achieved = FLOP_PER_SAMPLE_GRU128 * samples_per_step / avg_s / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("gru_layer_mid_bytes_per_launch")
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                    "kernel": "gru_layer_kernel<128,false>", "avg_launch_ms": ms / n,
+                    "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_step}
+        result = {
+            "metric": "signal samples/s classified",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 4096-sample reads, 256 reads (30208 windows of 35) "
+                                   "per step and GPU, fp32, ckpnt-30000 weights",
+                       "reads_per_step": READS_PER_STEP, "read_len": READ_LEN, "windows_per_step": READS_PER_STEP * 118,
+                       "parallelism": "reads sharded over %d GPU(s), no collective" % world},
+            "roofline": roof,
+            "whole_pass": {"achieved_tflops": value / world * FLOP_PER_SAMPLE / 1e12,
+                           "frac_of_f32_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "kernels_ms": {k: v[0] / v[1] for k, v in kern.items()},
+            "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match, "gate": 1e-4},
+        }
+        result["cpu_baseline"] = cpu_res
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,24 @@ SYMBOLS = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """One process must hold ONE HIP/ROCr runtime.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7).  If our
+    library pulled in the system copy first, torch would later load its bundled copy next to
+    it and the second ROCr instance finds no GPU ("No HIP GPUs are available").  Loading
+    torch's copy first makes the dynamic linker satisfy our NEEDED libamdhip64.so.7 with
+    that same object (soname match).  Without torch installed the system runtime is used.
+    """
+    try:
+        import torch
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load (once) and return the C-ABI library; raise loudly when it is absent."""
     global _lib
@@ -87,6 +105,7 @@ def lib():
             raise NativeLibraryMissing(
                 "%s not found: the HIP extension has not been built. Run "
                 "`python -m catfish_amd.build` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+        _preload_torch_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)
