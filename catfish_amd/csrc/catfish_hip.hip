@@ -363,12 +363,16 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, 
 
 // ------------------------------------------------------------------------------------------
 // Kernel 4: class_from_threshold + correct_short (infer.py:128-138,174-198) per read.
-// A positive sample survives iff its positive run (inside its own read) has length >= min_run.
+// Reads are packed back to back WITH their zero padding: read r owns samples
+// [read_offsets[r], read_offsets[r+1]) of which the first read_lengths[r] are real
+// (infer.py:47 trims the padding before thresholding).  A positive sample survives iff its
+// positive run inside the real part of its own read has length >= min_run.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ probs,
-                                                          const int64_t* __restrict__ read_offsets, int64_t n_reads,
-                                                          float threshold, int min_run, uint8_t* __restrict__ labels) {
-    const int64_t total = read_offsets[n_reads];
+                                                          const int64_t* __restrict__ read_offsets,
+                                                          const int64_t* __restrict__ read_lengths, int64_t n_reads,
+                                                          int64_t total, float threshold, int min_run,
+                                                          uint8_t* __restrict__ labels) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     uint8_t out = 0;
@@ -379,11 +383,13 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
             const int64_t mid = (lo + hi) >> 1;
             if (read_offsets[mid] <= i) lo = mid; else hi = mid;
         }
-        const int64_t beg = read_offsets[lo], end = read_offsets[lo + 1];
-        int run = 1;
-        for (int64_t j = i - 1; j >= beg && run < min_run && probs[j] >= threshold; --j) ++run;
-        for (int64_t j = i + 1; j < end && run < min_run && probs[j] >= threshold; ++j) ++run;
-        out = run >= min_run ? 1 : 0;
+        const int64_t beg = read_offsets[lo], end = beg + read_lengths[lo];
+        if (i < end) {
+            int run = 1;
+            for (int64_t j = i - 1; j >= beg && run < min_run && probs[j] >= threshold; --j) ++run;
+            for (int64_t j = i + 1; j < end && run < min_run && probs[j] >= threshold; ++j) ++run;
+            out = run >= min_run ? 1 : 0;
+        }
     }
     labels[i] = out;
 }
@@ -734,23 +740,21 @@ extern "C" int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, flo
     return rc;
 }
 
-extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets, int64_t n_reads, float threshold,
-                              int32_t min_run, uint8_t* labels, void* stream) {
+extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets, const int64_t* read_lengths,
+                              int64_t n_reads, int64_t total_samples, float threshold, int32_t min_run, uint8_t* labels,
+                              void* stream) {
     if (!m) return fail(CF_ERR_INVALID, "cf_postprocess: null model");
-    if (n_reads < 0) return fail(CF_ERR_INVALID, "cf_postprocess: negative n_reads");
-    if (n_reads == 0) return CF_OK;
-    if (!probs || !read_offsets || !labels) return fail(CF_ERR_INVALID, "cf_postprocess: null buffer");
+    if (n_reads < 0 || total_samples < 0) return fail(CF_ERR_INVALID, "cf_postprocess: negative size");
+    if (n_reads == 0 || total_samples == 0) return CF_OK;
+    if (min_run < 1) return fail(CF_ERR_INVALID, "cf_postprocess: min_run must be >= 1");
+    if (!probs || !read_offsets || !read_lengths || !labels) return fail(CF_ERR_INVALID, "cf_postprocess: null buffer");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, read_offsets + n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (total <= 0) return CF_OK;
     size_t pi = 0;
     int rc = prof_begin(m, SLOT_POST, s, &pi);
     if (rc != CF_OK) return rc;
-    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probs, read_offsets, n_reads,
-                       threshold, (int)min_run, labels);
+    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, probs, read_offsets,
+                       read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
 }

@@ -87,22 +87,30 @@ class HipEngine(object):
                                    C.c_void_p(stream.cuda_stream)))
         return out
 
-    def postprocess_device(self, probs, read_offsets, threshold=0.5, min_run=15, out=None, stream=None):
-        """Device threshold + correct_short: float32 probs, int64 read_offsets[n_reads+1] -> uint8 labels."""
+    def postprocess_device(self, probs, read_offsets, read_lengths, threshold=0.5, min_run=15, out=None, stream=None):
+        """Device threshold + correct_short over packed padded reads.
+
+        probs: float32 CUDA [total]; read_offsets: int64 CUDA [n_reads+1] (padded sample offsets);
+        read_lengths: int64 CUDA [n_reads] (real lengths) -> uint8 CUDA labels [total] (padding = 0).
+        """
         import torch
         if not probs.is_cuda or probs.dtype != torch.float32 or not probs.is_contiguous():
             raise ValueError("probs must be a contiguous float32 CUDA tensor")
-        if read_offsets.dtype != torch.int64 or not read_offsets.is_cuda:
-            raise ValueError("read_offsets must be an int64 CUDA tensor")
-        n_reads = int(read_offsets.numel()) - 1
+        for t in (read_offsets, read_lengths):
+            if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("read_offsets/read_lengths must be contiguous int64 CUDA tensors")
+        n_reads = int(read_lengths.numel())
+        if int(read_offsets.numel()) != n_reads + 1:
+            raise ValueError("read_offsets must have n_reads + 1 entries")
+        total = int(probs.numel())
         if out is None:
-            out = torch.empty(probs.numel(), dtype=torch.uint8, device=probs.device)
+            out = torch.empty(total, dtype=torch.uint8, device=probs.device)
         if stream is None:
             stream = torch.cuda.current_stream(probs.device)
         N.check(self._lib.cf_postprocess(self._handle, C.c_void_p(probs.data_ptr()),
-                                         C.c_void_p(read_offsets.data_ptr()), n_reads, float(threshold),
-                                         int(min_run), C.c_void_p(out.data_ptr()),
-                                         C.c_void_p(stream.cuda_stream)))
+                                         C.c_void_p(read_offsets.data_ptr()), C.c_void_p(read_lengths.data_ptr()),
+                                         n_reads, total, float(threshold), int(min_run),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream)))
         return out
 
     # ------------------------------------------------------------------ profiling / debug

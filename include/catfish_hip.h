@@ -100,13 +100,18 @@ int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* probs, void*
 int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, float* probs);
 
 /* Read-level post-processing on device, replacing class_from_threshold +
- * correct_short (catfish/infer.py:128-138,174-198): labels[i] = 1 iff
- * probs[i] >= threshold and i lies in a positive run of length >= min_run
- * inside its read.  Reads are given by read_offsets[n_reads + 1] (sample
- * offsets into probs, device pointer, int64).  labels: device uint8. */
+ * correct_short (catfish/infer.py:128-138,174-198).  Reads are packed back to
+ * back INCLUDING their zero padding (infer.py:31-38): read r owns samples
+ * [read_offsets[r], read_offsets[r+1]) of probs, of which the first
+ * read_lengths[r] are real (the reference trims the padding at infer.py:47).
+ * labels[i] = 1 iff probs[i] >= threshold and i lies in a positive run of
+ * length >= min_run inside the real part of its read; padding gets 0.
+ * read_offsets: device int64[n_reads + 1]; read_lengths: device int64[n_reads];
+ * total_samples = read_offsets[n_reads] (passed by value so that the call
+ * stays asynchronous); labels: device uint8[total_samples]. */
 int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets,
-                   int64_t n_reads, float threshold, int32_t min_run,
-                   uint8_t* labels, void* stream);
+                   const int64_t* read_lengths, int64_t n_reads, int64_t total_samples,
+                   float threshold, int32_t min_run, uint8_t* labels, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, 1) makes every cf_infer record

@@ -1,0 +1,92 @@
+"""Checkpoint-V2 reader KATs: per-tensor masked CRC-32C, name/shape/offset table."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from catfish_amd import checkpoint
+from conftest import GOLDEN, REFERENCE, has_reference
+
+CKPT_DIR = os.path.join(REFERENCE, "catfish", "ResNetRNN", "checkpoints")
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test vectors
+    assert checkpoint.crc32c(b"123456789") == 0xE3069283
+    assert checkpoint.crc32c(bytes(32)) == 0x8A9136AA
+    assert checkpoint.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    # conv1d/kernel crc 0x39d6f2c1 is stored masked as 0x88055e85
+    assert checkpoint.mask_crc(0x39D6F2C1) == 0x88055E85
+    assert checkpoint.unmask_crc(0x88055E85) == 0x39D6F2C1
+
+
+def test_table_fixture_shape_facts():
+    with open(os.path.join(GOLDEN, "ckpt_table.json")) as fh:
+        table = {e["name"]: e for e in json.load(fh)}
+    assert len(table) == 190
+    inf = [n for n in table if checkpoint.is_inference_tensor(n)]
+    assert len(inf) == 74
+    assert table["batch_normalization/beta"]["offset"] == 0
+    assert table["batch_normalization/gamma"]["offset"] == 384
+    assert table["conv1d/bias"]["offset"] == 8192
+    assert table["conv1d/kernel"]["offset"] == 8576
+    assert table["conv1d_2/kernel"]["offset"] == 10112 and table["conv1d_2/kernel"]["size"] == 12288
+    assert table["final_fully_connected/kernel"]["offset"] == 134924
+    assert table["conv1d/kernel"]["crc32c"] == 0x88055E85
+    assert sum(int(np.prod(table[n]["shape"])) for n in inf) == 197185
+
+
+@pytest.mark.skipif(not has_reference(), reason="reference checkpoint not mounted")
+def test_reference_bundle_matches_fixture_and_crcs(ckpt_weights):
+    entries = checkpoint.read_index(os.path.join(CKPT_DIR, "ckpnt-30000.index"))
+    with open(os.path.join(GOLDEN, "ckpt_table.json")) as fh:
+        table = json.load(fh)
+    assert [e.as_dict() for e in entries.values()] == table
+    w = checkpoint.read_inference_weights(CKPT_DIR, "ckpnt-30000")     # verifies every CRC
+    assert sorted(w) == sorted(ckpt_weights)
+    for k in w:
+        assert np.array_equal(w[k], ckpt_weights[k]), k
+    # "latest" resolution (no `checkpoint` state file in the bundle -> highest step)
+    w2 = checkpoint.read_inference_weights(CKPT_DIR, "latest")
+    assert np.array_equal(w2["conv1d/kernel"], w["conv1d/kernel"])
+
+
+def test_checkpoint_fingerprints(ckpt_weights):
+    """BN moving stats are exactly 0/1, GRU gate biases sit near their init of 1."""
+    for j in range(8):
+        bn = "batch_normalization" if j == 0 else "batch_normalization_%d" % j
+        assert np.all(ckpt_weights[bn + "/moving_mean"] == 0)
+        assert np.all(ckpt_weights[bn + "/moving_variance"] == 1)
+    for l in range(3):
+        for d in ("fw", "bw"):
+            b = ckpt_weights["stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell/gates/bias" % (l, d)]
+            assert 0.5 < b.mean() < 1.5
+
+
+def test_write_read_round_trip(tmp_path, ckpt_weights):
+    prefix = str(tmp_path / "ckpts" / "ckpnt-7")
+    extra = dict(ckpt_weights)
+    extra["conv1d/kernel/RMSProp"] = np.zeros((1, 1, 32), np.float32)   # optimizer slot: must be skipped
+    checkpoint.write_checkpoint(prefix, extra)
+    entries = checkpoint.read_index(prefix + ".index")
+    assert len(entries) == 75
+    back = checkpoint.read_inference_weights(str(tmp_path / "ckpts"), "latest")
+    assert len(back) == 74
+    for k in ckpt_weights:
+        assert np.array_equal(back[k], ckpt_weights[k])
+    back2 = checkpoint.read_inference_weights(str(tmp_path / "ckpts"), "ckpnt-7")
+    assert sorted(back2) == sorted(back)
+
+
+def test_corruption_is_detected(tmp_path, ckpt_weights):
+    prefix = str(tmp_path / "ckpnt-1")
+    checkpoint.write_checkpoint(prefix, {"conv1d/kernel": ckpt_weights["conv1d/kernel"]})
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[5] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc32c"):
+        checkpoint.read_checkpoint(prefix)
+    with pytest.raises(KeyError):
+        checkpoint.read_checkpoint(prefix, ["nope"], verify_crc=False)

@@ -1,0 +1,145 @@
+"""GPU tests of the read-level pipeline and of full-size properties (through the C ABI)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import catfish_oracle as oracle
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(hp):
+    from catfish_amd.resnet_class import ResNetRNN
+    m = ResNetRNN(**hp)
+    with np.load(os.path.join(GOLDEN, "ckpnt-30000-inference.npz")) as z:
+        m.set_weights({k: z[k] for k in z.files})
+    yield m
+    m.engine.close()
+
+
+def test_model_infer_surface(model, golden_read):
+    x = golden_read["x"][:, :, None].astype(np.float64)      # reference feeds float64 [N,35,1]
+    out = model.infer(x)
+    assert out.dtype == np.float64 and out.shape == (118 * 35,)
+    assert np.abs(out - golden_read["probs_fp64"]).max() < 1e-4
+
+
+def test_infer_class_from_raw_matches_oracle(model, ckpt_weights):
+    from catfish_amd import infer
+    for seed, n in ((1, 4096), (2, 700), (3, 35), (4, 36), (5, 1)):
+        dac = oracle.synthetic_dac(1, max(n, 2), seed=seed)[0][:n]
+        sig = oracle.normalize_raw_signal(dac) if n > 1 else np.array([0.3])
+        spans, length = infer.infer_class_from_raw(sig, model)
+        w_spans, w_len, _ = oracle.infer_read(sig, ckpt_weights, np.float32)
+        assert length == w_len == n
+        assert spans == w_spans
+
+
+def test_infer_class_from_signal_npy_and_errors(model, tmp_path, ckpt_weights):
+    from catfish_amd import infer
+    dac = oracle.synthetic_dac(1, 2000, seed=9)[0]
+    p = tmp_path / "read0.npy"
+    np.save(p, dac)
+    spans, length = infer.infer_class_from_signal(str(p), model)
+    w_spans, w_len, _ = oracle.infer_read(oracle.normalize_raw_signal(dac), ckpt_weights, np.float32)
+    assert (spans, length) == (w_spans, w_len)
+    with pytest.raises(ValueError):
+        infer.infer_class_from_signal(str(tmp_path / "missing.fast5"), model)
+
+
+def test_test_network_counters(model, golden_read):
+    x = golden_read["x"][:, :, None]
+    y = (golden_read["probs_fp64"] >= 0.5).astype(np.float64).reshape(-1, 35, 1)
+    acc, loss = model.test_network(x, y, "read", "", padding_size=34)
+    assert acc == 1.0 and loss > 0
+    assert model.tp + model.fn == int(y.sum())
+    assert model.fp == 0 and model.fn == 0
+
+
+def test_postprocess_kernel_matches_reference_semantics(model):
+    torch = pytest.importorskip("torch")
+    from catfish_amd import batching
+    rng = np.random.default_rng(0)
+    lens = [1, 14, 15, 16, 35, 36, 700, 4096, 70]
+    sigs = [np.zeros(n) for n in lens]
+    pk = batching.pack_reads(sigs)
+    probs = np.zeros(pk.n_windows * 35, dtype=np.float32)
+    per_read = []
+    for i, n in enumerate(lens):
+        base = np.cumsum(rng.normal(0, 0.15, size=n)) + rng.normal(0, 0.3)
+        p = (1 / (1 + np.exp(-base))).astype(np.float32)
+        per_read.append(p)
+        probs[pk.sample_offsets[i]:pk.sample_offsets[i] + n] = p
+    # padding deliberately filled with ones: it must still come out as 0
+    mask = np.ones_like(probs, dtype=bool)
+    for i, n in enumerate(lens):
+        mask[pk.sample_offsets[i]:pk.sample_offsets[i] + n] = False
+    probs[mask] = 1.0
+    dev = torch.device("cuda", 0)
+    labels = model.engine.postprocess_device(torch.from_numpy(probs).to(dev),
+                                             torch.from_numpy(pk.sample_offsets).to(dev),
+                                             torch.from_numpy(pk.lengths).to(dev)).cpu().numpy()
+    assert labels[mask].sum() == 0
+    for i, n in enumerate(lens):
+        want = oracle.correct_short(oracle.class_from_threshold(per_read[i]))
+        got = labels[pk.sample_offsets[i]:pk.sample_offsets[i] + n]
+        assert np.array_equal(got, want), i
+    spans = batching.spans_from_labels(labels, pk.sample_offsets, pk.n_reads)
+    for i, n in enumerate(lens):
+        want = oracle.correct_short(oracle.class_from_threshold(per_read[i]))
+        assert spans[i] == (oracle.hp_in_pred(want) if want.any() else [])
+
+
+def test_packed_variable_length_reads_match_per_read_oracle(model, ckpt_weights):
+    """Config-4 shape: ragged reads 512..16384 in length-bucketed packed launches."""
+    from catfish_amd import batching
+    rng = np.random.default_rng(2)
+    lens = np.exp(rng.uniform(np.log(512), np.log(16384), size=12)).astype(int).tolist() + [35, 70, 1]
+    sigs = []
+    for i, n in enumerate(lens):
+        dac = oracle.synthetic_dac(1, max(n, 2), seed=100 + i)[0][:n]
+        sigs.append(oracle.normalize_raw_signal(dac) if n > 1 else np.array([0.1]))
+    got = batching.infer_reads(model, sigs, max_windows=1024)
+    for s, g in zip(sigs, got):
+        w_spans, w_len, _ = oracle.infer_read(s, ckpt_weights, np.float32)
+        assert g == (w_spans, w_len)
+
+
+def test_full_size_properties(model):
+    """BASELINE size (256 reads x 118 windows): window-permutation equivariance, batch-split
+    invariance and run-to-run determinism -- size-independent properties of independent windows."""
+    torch = pytest.importorskip("torch")
+    eng = model.engine
+    n = 256 * 118
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(n, 35, generator=g).mul_(1.5).cuda()
+    a = eng.infer_device(x).clone()
+    b = eng.infer_device(x).clone()
+    assert torch.equal(a, b)                                   # deterministic
+    perm = torch.randperm(n, generator=g).cuda()
+    c = eng.infer_device(x[perm].contiguous()).view(n, 35)
+    assert torch.equal(c, a.view(n, 35)[perm])                 # windows independent, bit-exact
+    half = eng.infer_device(x[: n // 2 + 7].contiguous())
+    assert torch.equal(half, a[: (n // 2 + 7) * 35])           # split point does not matter
+    assert torch.isfinite(a).all() and (a > 0).all() and (a < 1).all()
+    # spot-check 32 random windows of the big batch against the oracle
+    idx = torch.randint(0, n, (32,), generator=g)
+    with np.load(os.path.join(GOLDEN, "ckpnt-30000-inference.npz")) as z:
+        w = {k: z[k] for k in z.files}
+    want = oracle.forward(x[idx.cuda()].cpu().numpy(), w, np.float64).reshape(32, 35)
+    got = a.view(n, 35)[idx.cuda()].cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
+
+
+def test_extreme_inputs_saturate_cleanly(model):
+    x = np.zeros((32, 35), np.float32)
+    x[0] = 1e4; x[1] = -1e4; x[2, ::2] = 300; x[3] = np.linspace(-50, 50, 35)
+    out = model.engine.infer_host(x)
+    assert np.isfinite(out).all()
+    with np.load(os.path.join(GOLDEN, "ckpnt-30000-inference.npz")) as z:
+        w = {k: z[k] for k in z.files}
+    want = oracle.forward(x, w, np.float64)
+    assert np.abs(out - want).max() < 1e-4

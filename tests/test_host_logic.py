@@ -1,0 +1,194 @@
+"""Host-side logic of the product (no GPU): vectorised post-processing, packing, sharding, CLI tail,
+hyper-parameter parser, operator-surface error behaviour, C-ABI symbol table."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from catfish_amd import batching, cli, infer, metrics, neural_network, sharding
+from catfish_amd import _native
+from oracle import catfish_oracle as oracle
+from conftest import GOLDEN, REFERENCE, ROOT, has_reference
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(GOLDEN, "postproc_golden.json")) as fh:
+        return json.load(fh)
+
+
+def test_postprocessing_matches_reference_goldens(golden):
+    for c in golden["postproc"]:
+        labels = infer.class_from_threshold(c["scores"])
+        assert labels == c["labels"]
+        corrected = infer.correct_short(labels)
+        assert corrected.tolist() == c["corrected"]
+        assert infer.hp_in_pred(corrected) == c["spans"]
+        assert all(isinstance(v, int) for s in infer.hp_in_pred(corrected) for v in s)
+
+
+def test_postprocessing_matches_oracle_on_random_inputs():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 29, 30, 31, 500, 5000):
+        p = rng.random(n) < rng.choice([0.2, 0.5, 0.8, 0.95])
+        lab = p.astype(int)
+        assert np.array_equal(infer.correct_short(lab), oracle.correct_short(lab))
+        assert infer.hp_in_pred(lab) == oracle.hp_in_pred(lab)
+        assert infer.hp_in_pred(lab, 0, 0, label=0) == oracle.hp_in_pred(lab, 0, 0, label=0)
+
+
+def test_postprocessing_empty_raises_like_reference():
+    with pytest.raises(IndexError):
+        infer.correct_short([])
+    with pytest.raises(IndexError):
+        infer.hp_in_pred([])
+
+
+def test_normalisation_and_padding(golden):
+    for c in golden["normalize"]:
+        out = infer.normalize_raw_signal(np.array(c["raw"], dtype=np.int16), "median")
+        assert np.array_equal(out, np.array(c["out"]))
+    with pytest.raises(ValueError):
+        infer.normalize_raw_signal(np.arange(4), "mean")
+    for c in golden["padding"]:
+        assert infer.padding_size_for(c["length"]) == c["padding_size"]
+    with pytest.raises(ValueError):
+        infer.load_raw("/nonexistent/read.fast5")
+
+
+def test_cli_tail_matches_reference(golden):
+    for c in golden["center_hp"]:
+        out = cli.center_hp([[0, 5], list(c["in"])], c["len_read"], c["chunk_size"])
+        assert out[-1] == c["out"]
+    for c in golden["merge"]:
+        merged = cli.merge_positions([list(s) for s in c["spans"]], c["len_read"], c["chunk_size"])
+        assert merged == c["merged"]
+        assert cli.nonhp_complement(merged, c["len_read"]) == c["nonhp"]
+
+
+def test_cli_options_match_reference():
+    main = cli._build_click_main()
+    opts = {o.name: o for o in main.params}
+    assert set(opts) == {"input_dir", "split_dir", "chunk_size"}
+    assert opts["input_dir"].opts == ["--input-dir", "-i"]
+    assert opts["split_dir"].opts == ["--split-dir", "-s"]
+    assert opts["chunk_size"].opts == ["--chunk-size", "-c"] and opts["chunk_size"].default == 1000
+
+
+def test_pack_reads_layout():
+    rng = np.random.default_rng(0)
+    lens = [1, 34, 35, 36, 70, 512, 4096]
+    sigs = [rng.normal(size=n) for n in lens]
+    pk = batching.pack_reads(sigs)
+    want_win = [oracle.pad_and_window(s)[0].shape[0] for s in sigs]
+    assert np.array_equal(np.diff(pk.win_offsets), want_win)
+    for i, s in enumerate(sigs):
+        x, pad = oracle.pad_and_window(s)
+        got = pk.x[pk.win_offsets[i]:pk.win_offsets[i + 1]]
+        assert np.array_equal(got, x[:, :, 0].astype(np.float32))
+    assert pk.n_windows == sum(want_win) and pk.n_reads == len(lens)
+
+
+def test_length_buckets_cover_all_reads_once():
+    rng = np.random.default_rng(2)
+    lens = np.exp(rng.uniform(np.log(512), np.log(16384), size=300)).astype(int)
+    buckets = batching.length_buckets(lens, max_windows=4096)
+    flat = sorted(i for b in buckets for i in b)
+    assert flat == list(range(300))
+    for b in buckets:
+        w = sum(sharding.windows_of(lens[i]) for i in b)
+        assert w <= 4096 or len(b) == 1
+
+
+def test_spans_from_packed_labels_match_per_read_reference_logic():
+    rng = np.random.default_rng(5)
+    lens = [40, 35, 700, 123, 70]
+    sigs = [np.zeros(n) for n in lens]
+    pk = batching.pack_reads(sigs)
+    labels = np.zeros(pk.n_windows * 35, dtype=np.uint8)
+    per_read = []
+    for i, n in enumerate(lens):
+        lab = (rng.random(n) < 0.7).astype(int)
+        lab = oracle.correct_short(lab)
+        per_read.append(lab)
+        labels[pk.sample_offsets[i]:pk.sample_offsets[i] + n] = lab
+    got = batching.spans_from_labels(labels, pk.sample_offsets, pk.n_reads)
+    for i, lab in enumerate(per_read):
+        want = oracle.hp_in_pred(lab) if lab.any() else []
+        assert got[i] == want
+
+
+def test_shard_reads_balanced_and_complete():
+    rng = np.random.default_rng(7)
+    lens = np.exp(rng.uniform(np.log(512), np.log(16384), size=1000)).astype(int)
+    for world in (1, 2, 4, 8):
+        shards = sharding.shard_reads(lens, world)
+        assert sorted(i for s in shards for i in s) == list(range(1000))
+        loads = [sum(sharding.windows_of(lens[i]) for i in s) for s in shards]
+        assert max(loads) - min(loads) <= sharding.windows_of(16384)
+    eq = sharding.shard_reads([4096] * 100000, 8)
+    assert [len(s) for s in eq] == [12500] * 8
+
+
+def test_confusion_matrix():
+    assert metrics.confusion_matrix([1, 0, 1, 0], [1, 1, 0, 0]) == (1, 1, 1, 1)
+    with pytest.raises(ValueError):
+        metrics.confusion_matrix([1], [1, 0])
+
+
+def test_hyperparams_parser(tmp_path):
+    f = tmp_path / "ResNetRNN.txt"
+    f.write_text("MODEL TYPE: ResNet-RNN\n\nbatch_size: 256\noptimizer_choice: RMSProp\nlearning_rate: 0.001\n"
+                 "layer_size: 64\nn_layers: 3\nkeep_prob: 0.8\nlayer_size_res: 32\nn_layers_res: 2\n\n"
+                 "NEXT EPOCH\n\tAccuracy: 88.67%\n")
+    hp = neural_network.retrieve_hyperparams(str(f))
+    assert hp == dict(batch_size=256, optimizer_choice="RMSProp", learning_rate=0.001, layer_size=64,
+                      n_layers=3, keep_prob=0.8, layer_size_res=32, n_layers_res=2)
+    if has_reference():
+        assert neural_network.retrieve_hyperparams(os.path.join(REFERENCE, "catfish/ResNetRNN/ResNetRNN.txt")) == hp
+
+
+def test_model_surface_and_errors(hp):
+    from catfish_amd.resnet_class import ResNetRNN
+    from catfish_amd.rnn_class import RNN
+    m = ResNetRNN(**hp)
+    assert (m.window, m.n_inputs, m.n_outputs, m.batch_size) == (35, 1, 1, 256)
+    assert m.model_type == "ResNet-RNN" and (m.tp, m.fp, m.tn, m.fn) == (0, 0, 0, 0)
+    assert RNN(**hp).model_type == "biGRU-RNN"
+    bad = dict(hp, optimizer_choice="SGD")
+    with pytest.raises(ValueError, match="optimizer"):
+        ResNetRNN(**bad)
+    with pytest.raises(RuntimeError):
+        m.infer(np.zeros((1, 35, 1)))
+    with pytest.raises(KeyError):
+        ResNetRNN(batch_size=1)
+    w = m._initial_weights(seed=0)
+    assert len(w) == 74 and w["conv1d_2/kernel"].shape == (3, 32, 32)
+    assert np.all(w["stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/gru_cell/gates/bias"] == 1)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The library loads and exports exactly what include/catfish_hip.h declares (no compute calls)."""
+    import re
+    header = open(os.path.join(ROOT, "include", "catfish_hip.h")).read()
+    declared = set(re.findall(r"\b(cf_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.SYMBOLS)
+    assert os.path.exists(_native.LIB_PATH), "run `python -m catfish_amd.build` first"
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], stdout=subprocess.PIPE,
+                         universal_newlines=True, check=True).stdout
+    exported = set(re.findall(r" T (cf_[a-z_]+)", out))
+    assert declared <= exported
+    lib = _native.lib()
+    assert b"gfx950" in lib.cf_version()
+    assert lib.cf_profile_slot_name(3) == b"gru_layer_mid"
+
+
+def test_product_never_imports_oracle():
+    import re
+    pkg = os.path.join(ROOT, "catfish_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), name
