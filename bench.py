@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pool-reads", type=int, default=2048, help="distinct synthetic reads per rank")
+    ap.add_argument("--streams", type=int, default=0, help="scratch slots/internal streams per engine (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable per-kernel HIP events")
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
 
     from catfish_amd.engine import HipEngine
     weights = load_weights()
-    eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118)
+    eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, n_streams=args.streams)
 
     # every rank owns its own shard of reads (seeded by rank): no data-path collective
     n_pool = max(READS_PER_STEP, (args.pool_reads // READS_PER_STEP) * READS_PER_STEP)

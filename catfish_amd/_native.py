@@ -28,7 +28,7 @@ class cf_hparams(C.Structure):
     _fields_ = [("layer_size", C.c_int32), ("n_layers", C.c_int32),
                 ("layer_size_res", C.c_int32), ("n_layers_res", C.c_int32),
                 ("window", C.c_int32), ("bn_epsilon", C.c_float),
-                ("max_windows_per_pass", C.c_int64)]
+                ("max_windows_per_pass", C.c_int64), ("n_streams", C.c_int32)]
 
 
 class cf_conv_bn(C.Structure):

@@ -423,13 +423,22 @@ struct cf_model {
     std::vector<int> gru_cin;
     float dense_bias = 0.f;
     // workspace
-    int64_t cap_windows = 0;
+    int64_t cap_windows = 0;              // per workspace slot
     int64_t cap_tiles = 0;
-    float* d_a[2] = {nullptr, nullptr};   // conv ping-pong, F = 32
-    float* d_y[2] = {nullptr, nullptr};   // GRU layer outputs ping-pong, F = 128
-    float* d_p = nullptr;                 // dense partials [2][tiles][35][16]
+    // A pass needs ~2.6 KB of scratch per sample; every slot owns one scratch set and one
+    // internal stream, so consecutive sub-batches overlap (the tail of one layer's grid leaves
+    // CUs idle that the other slot's kernels fill).
+    struct Slot {
+        float* d_a[2] = {nullptr, nullptr};   // conv ping-pong, F = 32
+        float* d_y[2] = {nullptr, nullptr};   // GRU layer outputs ping-pong, F = 128
+        float* d_p = nullptr;                 // dense partials [2][tiles][35][16]
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        int64_t last_windows = 0;             // windows of the last pass (debug hook)
+    };
+    std::vector<Slot> slots;
+    hipEvent_t fork = nullptr;
     int64_t ws_bytes = 0;
-    int64_t last_windows = 0;             // windows of the last pass (debug hook)
     // profiling
     bool prof = false;
     struct Ev { hipEvent_t a, b; int slot; };
@@ -543,8 +552,13 @@ extern "C" void cf_model_destroy(cf_model* m) {
     (void)hipSetDevice(m->device);
     for (float* p : m->d_res) if (p) (void)hipFree(p);
     for (float* p : m->d_gru) if (p) (void)hipFree(p);
-    for (int i = 0; i < 2; ++i) { if (m->d_a[i]) (void)hipFree(m->d_a[i]); if (m->d_y[i]) (void)hipFree(m->d_y[i]); }
-    if (m->d_p) (void)hipFree(m->d_p);
+    for (auto& sl : m->slots) {
+        for (int i = 0; i < 2; ++i) { if (sl.d_a[i]) (void)hipFree(sl.d_a[i]); if (sl.d_y[i]) (void)hipFree(sl.d_y[i]); }
+        if (sl.d_p) (void)hipFree(sl.d_p);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (m->fork) (void)hipEventDestroy(m->fork);
     for (auto& e : m->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
@@ -600,11 +614,19 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         const size_t y_bytes = (size_t)m->cap_tiles * CF_T * 8 * 64 * sizeof(f32x4);
         const size_t p_bytes = (size_t)2 * m->cap_tiles * CF_T * 16 * sizeof(float);
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&m->d_a[i], a_bytes);
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&m->d_y[i], y_bytes);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->d_p, p_bytes);
-        if (e != hipSuccess) rc = fail(CF_ERR_NOMEM, std::string("workspace hipMalloc: ") + hipGetErrorString(e));
-        m->ws_bytes = (int64_t)(2 * a_bytes + 2 * y_bytes + p_bytes);
+        int n_slots = hp->n_streams > 0 ? hp->n_streams : 1;   // measured: splitting one call over 2 internal streams is slower
+        if (n_slots > 8) n_slots = 8;
+        m->slots.resize(n_slots);
+        for (auto& sl : m->slots) {
+            for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&sl.d_a[i], a_bytes);
+            for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&sl.d_y[i], y_bytes);
+            if (e == hipSuccess) e = hipMalloc((void**)&sl.d_p, p_bytes);
+            if (e == hipSuccess && n_slots > 1) e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+            if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        }
+        if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(CF_ERR_NOMEM, std::string("workspace allocation: ") + hipGetErrorString(e));
+        m->ws_bytes = (int64_t)n_slots * (int64_t)(2 * a_bytes + 2 * y_bytes + p_bytes);
     }
     if (rc == CF_OK) {
         // opt in to > 64 KiB dynamic LDS for every GRU instantiation we may launch
@@ -657,14 +679,14 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
     return prof_end(m, s, pi);
 }
 
-static int run_pass(cf_model* m, const float* x, int64_t n_windows, float* probs, hipStream_t s) {
+static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_windows, float* probs, hipStream_t s) {
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
     int rc;
     size_t pi = 0;
     // residual blocks
     const int res_grid = std::min((n_tiles + 3) / 4, m->n_cu * 4);
     for (int b = 0; b < m->hp.n_layers_res; ++b) {
-        float* dst = m->d_a[b & 1];
+        float* dst = sl.d_a[b & 1];
         if (b == 0) {
             if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = (res_pack_floats(true) + 4 * CF_TILE * CF_T) * 4;
@@ -674,22 +696,22 @@ static int run_pass(cf_model* m, const float* x, int64_t n_windows, float* probs
             if ((rc = prof_begin(m, SLOT_RES, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = res_pack_floats(false) * 4;
             hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
-                               reinterpret_cast<const f32x4*>(m->d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
+                               reinterpret_cast<const f32x4*>(sl.d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         }
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     }
-    const float* cur = m->d_a[(m->hp.n_layers_res - 1) & 1];
+    const float* cur = sl.d_a[(m->hp.n_layers_res - 1) & 1];
     // GRU layers
     for (int l = 0; l < m->hp.n_layers; ++l) {
         const bool last = l == m->hp.n_layers - 1;
-        float* y = m->d_y[l & 1];
+        float* y = sl.d_y[l & 1];
         if (l == 0) {
-            rc = last ? launch_gru<32, true>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU_LAST)
-                      : launch_gru<32, false>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU0);
+            rc = last ? launch_gru<32, true>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU_LAST)
+                      : launch_gru<32, false>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU0);
         } else {
-            rc = last ? launch_gru<128, true>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU_LAST)
-                      : launch_gru<128, false>(m, m->d_gru[l], cur, y, m->d_p, n_tiles, s, SLOT_GRU);
+            rc = last ? launch_gru<128, true>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU_LAST)
+                      : launch_gru<128, false>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU);
         }
         if (rc != CF_OK) return rc;
         cur = y;
@@ -697,10 +719,10 @@ static int run_pass(cf_model* m, const float* x, int64_t n_windows, float* probs
     // head
     if ((rc = prof_begin(m, SLOT_HEAD, s, &pi)) != CF_OK) return rc;
     const int64_t total = n_windows * CF_T;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, m->d_p, m->dense_bias, probs, n_windows, n_tiles);
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sl.d_p, m->dense_bias, probs, n_windows, n_tiles);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
-    m->last_windows = n_windows;
+    sl.last_windows = n_windows;
     return CF_OK;
 }
 
@@ -711,10 +733,40 @@ extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* p
     if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer: null buffer");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    for (int64_t off = 0; off < n_windows; off += m->cap_windows) {
-        const int64_t n = std::min(m->cap_windows, n_windows - off);
-        const int rc = run_pass(m, x + off * CF_T, n, probs + off * CF_T, s);
+    const int n_slots = (int)m->slots.size();
+    // sub-batch size: split the call evenly over the slots, in whole 8-tile groups (128 windows)
+    int64_t chunk = m->cap_windows;
+    if (n_slots > 1) {
+        const int64_t per = ((n_windows + n_slots - 1) / n_slots + 127) / 128 * 128;
+        chunk = std::min(m->cap_windows, std::max<int64_t>(per, 128));
+    }
+    if (n_slots == 1 || n_windows <= 2048) {
+        // small calls (a single read) are launch-bound: no fork/join
+        for (int64_t off = 0; off < n_windows; off += m->cap_windows) {
+            const int64_t n = std::min(m->cap_windows, n_windows - off);
+            const int rc = run_pass(m, m->slots[0], x + off * CF_T, n, probs + off * CF_T, s);
+            if (rc != CF_OK) return rc;
+        }
+        if (n_slots > 1) {
+            // keep slot 0's scratch ordered against a later forked call on its internal stream
+            HIP_TRY(hipEventRecord(m->slots[0].done, s));
+            HIP_TRY(hipStreamWaitEvent(m->slots[0].stream, m->slots[0].done, 0));
+        }
+        return CF_OK;
+    }
+    // fork: every slot stream waits for the caller's stream, runs its sub-batches, joins back
+    HIP_TRY(hipEventRecord(m->fork, s));
+    for (auto& sl : m->slots) HIP_TRY(hipStreamWaitEvent(sl.stream, m->fork, 0));
+    int k = 0;
+    for (int64_t off = 0; off < n_windows; off += chunk, ++k) {
+        const int64_t n = std::min(chunk, n_windows - off);
+        cf_model::Slot& sl = m->slots[k % n_slots];
+        const int rc = run_pass(m, sl, x + off * CF_T, n, probs + off * CF_T, sl.stream);
         if (rc != CF_OK) return rc;
+    }
+    for (auto& sl : m->slots) {
+        HIP_TRY(hipEventRecord(sl.done, sl.stream));
+        HIP_TRY(hipStreamWaitEvent(s, sl.done, 0));
     }
     return CF_OK;
 }
@@ -801,18 +853,19 @@ extern "C" const char* cf_profile_slot_name(int slot) {
 // ---- debug hook --------------------------------------------------------------------------
 extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host) {
     if (!m || !out_host) return fail(CF_ERR_INVALID, "cf_debug_stage: null argument");
-    if (n_windows <= 0 || n_windows > m->last_windows) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds the last pass");
+    const cf_model::Slot& sl = m->slots[0];
+    if (n_windows <= 0 || n_windows > sl.last_windows) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds slot 0's last pass");
     HIP_TRY(hipSetDevice(m->device));
     int feats, mt;
     const float* src;
     if (stage >= 0 && stage < m->hp.n_layers_res) {
         // ping-pong: only the last two blocks survive a pass
         if (stage < m->hp.n_layers_res - 2) return fail(CF_ERR_INVALID, "cf_debug_stage: stage overwritten");
-        feats = CF_C; mt = 2; src = m->d_a[stage & 1];
+        feats = CF_C; mt = 2; src = sl.d_a[stage & 1];
     } else if (stage >= m->hp.n_layers_res && stage < m->hp.n_layers_res + m->hp.n_layers - 1) {
         const int l = stage - m->hp.n_layers_res;
         if (l < m->hp.n_layers - 3) return fail(CF_ERR_INVALID, "cf_debug_stage: stage overwritten");
-        feats = 2 * CF_H; mt = 8; src = m->d_y[l & 1];
+        feats = 2 * CF_H; mt = 8; src = sl.d_y[l & 1];
     } else {
         return fail(CF_ERR_INVALID, "cf_debug_stage: no such stage");
     }

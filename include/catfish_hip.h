@@ -46,7 +46,9 @@ typedef struct cf_hparams {
     int32_t n_layers_res;        /* residual blocks (resnet_class.py:10); 0 = RNN    */
     int32_t window;              /* must be 35                                       */
     float bn_epsilon;            /* tf.layers.batch_normalization epsilon (1e-3)     */
-    int64_t max_windows_per_pass;/* workspace capacity; longer inputs are chunked    */
+    int64_t max_windows_per_pass;/* scratch capacity per slot; longer inputs are chunked */
+    int32_t n_streams;           /* scratch slots + internal streams that overlap the
+                                    sub-batches of one call (0 = default 1 = none)       */
 } cf_hparams;
 
 /* One conv1d + batch_normalization pair, TF layout
