@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcatfish_hip.so")
+LIB_PATH = os.environ.get("CATFISH_HIP_LIB") or os.path.join(_HERE, "csrc", "libcatfish_hip.so")
 
 CF_OK = 0
 CF_ERR_INVALID = -1

@@ -39,6 +39,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Timing-only ablations (tools/ablate.sh builds variants; results are WRONG when set):
+//   bit 0: skip the sigmoid/tanh VALU phases   bit 1: no per-step global loads/stores
+//   bit 2: 4 waves per workgroup (one per SIMD) instead of 8
+#ifndef CF_ABLATE
+#define CF_ABLATE 0
+#endif
+#define CF_GRU_WAVES ((CF_ABLATE & 4) ? 4 : 8)
+
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
@@ -214,20 +222,22 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < PACK / 4; i += 512) dst[i] = src[i];
+        for (int i = threadIdx.x; i < PACK / 4; i += CF_GRU_WAVES * 64) dst[i] = src[i];
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4;
+    if (CF_ABLATE & 8) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_sleep(100); }
+    if (CF_ABLATE & 16) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_setprio(1); }
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;     // + (ks*3+g)*64
     const f32x4* WG = WX + XN4;                                        // + (ks*2+g)*64
     const f32x4* WC = WG + HG4;                                        // + ks*64
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;  // + mo*4
     const f32x4* D4 = reinterpret_cast<const f32x4*>(lds + DENSE) + q; // + m*4
 
-    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+    for (int tile = blockIdx.x * CF_GRU_WAVES + wave; tile < n_tiles; tile += gridDim.x * CF_GRU_WAVES) {
         f32x4 h[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // GRUCellZeroState
         f32x4 xc[KGX];
         {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
                 tn = tn < 0 ? 0 : (tn > CF_T - 1 ? CF_T - 1 : tn);
                 const f32x4* src = X + ((int64_t)tile * CF_T + tn) * KGX * 64 + lane;
 #pragma unroll
-                for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+                for (int g = 0; g < KGX; ++g) if (!(CF_ABLATE & 2)) xc[g] = src[g * 64];
             }
             // h part of the gates: [r | u] += Wh_g^T h          (gru_cell/MatMul)
 #pragma unroll
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rh[m][r] = cf_sigmoid(acc[m][r]) * h[m][r];
+                for (int r = 0; r < 4; ++r) rh[m][r] = (CF_ABLATE & 1) ? acc[m][r] * 0.001f : cf_sigmoid(acc[m][r]) * h[m][r];
             }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (CF_ABLATE & 1) { h[m][r] = acc[4 + m][r] * 0.001f + acc[8 + m][r] * 0.001f; continue; }
                     const float u = cf_sigmoid(acc[4 + m][r]);
                     const float c = cf_tanh(acc[8 + m][r]);
                     h[m][r] = fmaf(u, h[m][r] - c, c);
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
             if constexpr (!LAST) {
                 f32x4* dst = Y + (((int64_t)tile * CF_T + t) * 8 + dir * 4) * 64 + lane;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) dst[m * 64] = h[m];
+                for (int m = 0; m < 4; ++m) if (!(CF_ABLATE & 2) || s == CF_T - 1) dst[m * 64] = h[m];
             } else {
                 // partial logit of this direction: sum_f w[f] * h[f]   (final_fully_connected/MatMul)
                 float p = 0.f;
@@ -665,7 +676,7 @@ static int prof_end(cf_model* m, hipStream_t s, size_t idx) {
 
 template <int CIN, bool LAST>
 static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
-    const int groups = (n_tiles + 7) / 8;                       // one workgroup pass = 8 tiles (one per wave)
+    const int groups = (n_tiles + CF_GRU_WAVES - 1) / CF_GRU_WAVES;   // one workgroup pass = one tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;            // persistent: half the CUs per direction
     constexpr int lds_bytes = gru_pack_floats(CIN) * 4;
     if (lds_bytes <= 80 * 1024) per_dir *= 2;                   // two workgroups fit per CU
@@ -673,7 +684,7 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
     if (rc != CF_OK) return rc;
-    hipLaunchKernelGGL((gru_layer_kernel<CIN, LAST>), dim3(gx, 2), dim3(512), lds_bytes, s, wpack,
+    hipLaunchKernelGGL((gru_layer_kernel<CIN, LAST>), dim3(gx, 2), dim3(CF_GRU_WAVES * 64), lds_bytes, s, wpack,
                        reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
