@@ -32,6 +32,7 @@ WINDOW = 35
 FLOP_PER_SAMPLE = 389504            # SURVEY.md 8d / BASELINE.md 2 (2 x 194 752 MAC)
 FLOP_PER_SAMPLE_GRU128 = 2 * 2 * (128 + 64) * 192   # one CIN=128 biGRU layer: 2 dirs x 2 FLOP x 192x192 MAC
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 
 
 def make_reads(n_reads, seed):
@@ -72,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pool-reads", type=int, default=2048, help="distinct synthetic reads per rank")
     ap.add_argument("--streams", type=int, default=0, help="scratch slots/internal streams per engine (0 = library default)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the biGRU matmuls (fp32 = exact fp32 MFMA, the BASELINE configs[1] dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable per-kernel HIP events")
     args = ap.parse_args()
@@ -95,7 +98,8 @@ def main():
 
     from catfish_amd.engine import HipEngine
     weights = load_weights()
-    eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, n_streams=args.streams)
+    eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, n_streams=args.streams,
+                    precision=args.precision)
 
     # every rank owns its own shard of reads (seeded by rank): no data-path collective
     n_pool = max(READS_PER_STEP, (args.pool_reads // READS_PER_STEP) * READS_PER_STEP)
@@ -157,22 +161,29 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("gru_layer_mid_bytes_per_launch")
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "kernel": "gru_layer_kernel<128,false>", "avg_launch_ms": ms / n,
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            kname = "gru_layer_kernel<128,false>" if args.precision == "fp32" else \
+                "gru_layer_bf16_kernel<128,false,%d>" % (2 if args.precision == "bf16x3" else 1)
+            if args.precision != "fp32":
+                traffic = None      # profiles/traffic.json was collected for the fp32 kernel
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": traffic,
+                    "kernel": kname, "avg_launch_ms": ms / n,
                     "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_step}
         result = {
             "metric": "signal samples/s classified",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-operand fp32 emulation, f32 accumulate)",
+                                           "bf16": "bf16 (f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 4096-sample reads, 256 reads (30208 windows of 35) "
                                    "per step and GPU, fp32, ckpnt-30000 weights",
                        "reads_per_step": READS_PER_STEP, "read_len": READ_LEN, "windows_per_step": READS_PER_STEP * 118,
                        "parallelism": "reads sharded over %d GPU(s), no collective" % world},
             "roofline": roof,
             "whole_pass": {"achieved_tflops": value / world * FLOP_PER_SAMPLE / 1e12,
-                           "frac_of_f32_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                           "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 /
+                           (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS)},
             "kernels_ms": {k: v[0] / v[1] for k, v in kern.items()},
             "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match, "gate": 1e-4},
         }

@@ -26,7 +26,9 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    newest = max(os.path.getmtime(p) for p in (SRC, HEADER))
+    csrc = os.path.dirname(SRC)
+    deps = [HEADER] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".h"))]
+    newest = max(os.path.getmtime(p) for p in deps)
     return os.path.getmtime(OUT) < newest
 
 

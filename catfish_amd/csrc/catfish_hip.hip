@@ -108,7 +108,11 @@ __device__ __forceinline__ void unit_mma(const float* __restrict__ unit, int lan
     }
 }
 
-template <bool FIRST>
+// OUTP = 0: fp32 fragment layout (tile16) for the next fp32 kernel.
+// OUTP = 1/2: bf16 parts in the 32-window B-operand layout of gru_layer_bf16_kernel
+//             ([tile32][t][kb < 2][part < OUTP][lane][8 bf16]); a lane (window w, quarter q, M-tile m) owns
+//             elements j = 4(q>>1)..+3 of lane-half q&1, k-block m.
+template <bool FIRST, int OUTP>
 __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict__ wpack,
                                                         const float* __restrict__ x_nat,   // FIRST: [n_windows, 35]
                                                         const f32x4* __restrict__ x_frag,  // !FIRST: [tile][t][2][lane]
@@ -184,9 +188,27 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
                 f32x4 o2[2] = {relu4(acc[0]), relu4(acc[1])};                 // (:69-71)
                 f32x4 acc3[2] = {vec(VB3 + 1, 0), vec(VB3 + 1, 1)};
                 unit_mma(lds + (U3 + 3) * 1024, lane, o2, acc3);              // last conv (:74-76)
-                f32x4* dst = y_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
-                dst[0] = relu4(relu4(acc3[0]) + sc_p[0]);                     // add + relu (:79-80)
-                dst[64] = relu4(relu4(acc3[1]) + sc_p[1]);
+                const f32x4 o0 = relu4(relu4(acc3[0]) + sc_p[0]);             // add + relu (:79-80)
+                const f32x4 o1 = relu4(relu4(acc3[1]) + sc_p[1]);
+                if constexpr (OUTP == 0) {
+                    f32x4* dst = y_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
+                    dst[0] = o0;
+                    dst[64] = o1;
+                } else {
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    char* base = reinterpret_cast<char*>(y_frag) +
+                                 (((int64_t)(tile >> 1) * CF_T + (i - 1)) * 2 * OUTP) * 1024 +
+                                 ((q & 1) * 32 + (tile & 1) * 16 + (lane & 15)) * 16 + (q >> 1) * 8;
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo) {
+                        const f32x4 o = mo == 0 ? o0 : o1;
+                        bf16x4_t hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { hi[r] = (__bf16)o[r]; lo[r] = (__bf16)(o[r] - (float)hi[r]); }
+                        *reinterpret_cast<bf16x4_t*>(base + (mo * OUTP + 0) * 1024) = hi;
+                        if constexpr (OUTP == 2) *reinterpret_cast<bf16x4_t*>(base + (mo * OUTP + 1) * 1024) = lo;
+                    }
+                }
             }
 #pragma unroll
             for (int mo = 0; mo < 2; ++mo) { o1_pp[mo] = o1_p[mo]; o1_p[mo] = o1_c[mo]; sc_p[mo] = sc_c[mo]; }
@@ -356,19 +378,22 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
     }
 }
 
+#include "gru_bf16.hpp"
+
 // ------------------------------------------------------------------------------------------
 // Kernel 3: head -- logits = p_fw + p_bw + b, probs = sigmoid (rnn_class.py:84,179-181),
 // transposing the [tile][t][16] partials back to the reference's window-major order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, float bias, float* __restrict__ probs,
-                                                   int64_t n_windows, int n_tiles) {
+                                                   int64_t n_windows, int n_tiles, int tile_shift) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_windows * CF_T) return;
     const int64_t w = idx / CF_T;
     const int t = (int)(idx - w * CF_T);
-    const int64_t tile = w >> 4;
-    const int wl = (int)(w & 15);
-    const float z = P[((tile)*CF_T + t) * 16 + wl] + P[(((int64_t)n_tiles + tile) * CF_T + t) * 16 + wl] + bias;
+    const int64_t tile = w >> tile_shift;            // 16-window tiles (fp32 path) or 32-window tiles (bf16 path)
+    const int tw = 1 << tile_shift;
+    const int wl = (int)(w & (tw - 1));
+    const float z = P[((tile)*CF_T + t) * tw + wl] + P[(((int64_t)n_tiles + tile) * CF_T + t) * tw + wl] + bias;
     probs[idx] = 1.0f / (1.0f + expf(-z));
 }
 
@@ -432,6 +457,8 @@ struct cf_model {
     std::vector<float*> d_res;   // per residual block packed weights
     std::vector<float*> d_gru;   // per layer packed weights [2 dirs]
     std::vector<int> gru_cin;
+    std::vector<char*> d_gru_b;  // per layer packed bf16 weights [2 dirs] (precision != fp32)
+    int np = 0;                  // bf16 parts per operand: 0 = fp32 path, 1 = bf16, 2 = bf16x3
     float dense_bias = 0.f;
     // workspace
     int64_t cap_windows = 0;              // per workspace slot
@@ -563,6 +590,7 @@ extern "C" void cf_model_destroy(cf_model* m) {
     (void)hipSetDevice(m->device);
     for (float* p : m->d_res) if (p) (void)hipFree(p);
     for (float* p : m->d_gru) if (p) (void)hipFree(p);
+    for (char* p : m->d_gru_b) if (p) (void)hipFree(p);
     for (auto& sl : m->slots) {
         for (int i = 0; i < 2; ++i) { if (sl.d_a[i]) (void)hipFree(sl.d_a[i]); if (sl.d_y[i]) (void)hipFree(sl.d_y[i]); }
         if (sl.d_p) (void)hipFree(sl.d_p);
@@ -589,9 +617,12 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
     if (device < 0 || device >= n_dev) return fail(CF_ERR_INVALID, "device index out of range");
     HIP_TRY(hipSetDevice(device));
 
+    if (hp->precision < CF_PREC_FP32 || hp->precision > CF_PREC_BF16)
+        return fail(CF_ERR_INVALID, "precision must be CF_PREC_FP32, CF_PREC_BF16X3 or CF_PREC_BF16");
     cf_model* m = new cf_model();
     m->hp = *hp;
     m->device = device;
+    m->np = hp->precision == CF_PREC_FP32 ? 0 : (hp->precision == CF_PREC_BF16X3 ? 2 : 1);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
     int rc = CF_OK;
@@ -613,12 +644,23 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         rc = upload(blob, &dptr);
         m->d_gru.push_back(dptr);
         m->gru_cin.push_back(cin);
+        if (rc == CF_OK && m->np > 0) {
+            const size_t bytes = (size_t)gb_pack_bytes(cin, m->np);
+            std::vector<char> bblob(2 * bytes, 0);
+            for (int d = 0; d < 2; ++d)
+                pack_gru_dir_bf16(w->gru[2 * l + d], cin, m->np, last ? w->dense_kernel + d * CF_H : nullptr, bblob.data() + d * bytes);
+            char* bptr = nullptr;
+            hipError_t e = hipMalloc((void**)&bptr, bblob.size());
+            if (e == hipSuccess) e = hipMemcpy(bptr, bblob.data(), bblob.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = fail(CF_ERR_HIP, std::string("bf16 weight upload: ") + hipGetErrorString(e));
+            m->d_gru_b.push_back(bptr);
+        }
     }
     m->dense_bias = w->dense_bias[0];
     // workspace
     if (rc == CF_OK) {
         int64_t cap = hp->max_windows_per_pass > 0 ? hp->max_windows_per_pass : 32768;
-        cap = (cap + CF_TILE - 1) / CF_TILE * CF_TILE;
+        cap = (cap + 2 * CF_TILE - 1) / (2 * CF_TILE) * (2 * CF_TILE);   // whole 32-window tiles (bf16 path)
         m->cap_windows = cap;
         m->cap_tiles = cap / CF_TILE;
         const size_t a_bytes = (size_t)m->cap_tiles * CF_T * 2 * 64 * sizeof(f32x4);
@@ -647,6 +689,14 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_layer_kernel<32, true>, gru_pack_floats(32) * 4);
         optin((const void*)gru_layer_kernel<128, false>, gru_pack_floats(128) * 4);
         optin((const void*)gru_layer_kernel<128, true>, gru_pack_floats(128) * 4);
+        optin((const void*)gru_layer_bf16_kernel<32, false, 1>, gb_pack_bytes(32, 1));
+        optin((const void*)gru_layer_bf16_kernel<32, true, 1>, gb_pack_bytes(32, 1));
+        optin((const void*)gru_layer_bf16_kernel<128, false, 1>, gb_pack_bytes(128, 1));
+        optin((const void*)gru_layer_bf16_kernel<128, true, 1>, gb_pack_bytes(128, 1));
+        optin((const void*)gru_layer_bf16_kernel<32, false, 2>, gb_pack_bytes(32, 2));
+        optin((const void*)gru_layer_bf16_kernel<32, true, 2>, gb_pack_bytes(32, 2));
+        optin((const void*)gru_layer_bf16_kernel<128, false, 2>, gb_pack_bytes(128, 2));
+        optin((const void*)gru_layer_bf16_kernel<128, true, 2>, gb_pack_bytes(128, 2));
         if (e != hipSuccess) rc = fail(CF_ERR_HIP, std::string("hipFuncSetAttribute(max dynamic LDS): ") + hipGetErrorString(e));
     }
     if (rc != CF_OK) { std::string keep = g_err; cf_model_destroy(m); g_err = keep; return rc; }
@@ -690,8 +740,35 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
     return prof_end(m, s, pi);
 }
 
+template <int CIN, bool LAST, int NP>
+static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float* Y, float* P, int n_tiles32, hipStream_t s, int slot) {
+    const int groups = (n_tiles32 + 7) / 8;                      // one workgroup pass = 8 tiles of 32 windows
+    int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;
+    constexpr int lds_bytes = gb_pack_bytes(CIN, NP);
+    if (lds_bytes <= 80 * 1024) per_dir *= 2;
+    const int gx = groups < per_dir ? groups : per_dir;
+    size_t pi = 0;
+    int rc = prof_begin(m, slot, s, &pi);
+    if (rc != CF_OK) return rc;
+    hipLaunchKernelGGL((gru_layer_bf16_kernel<CIN, LAST, NP>), dim3(gx, 2), dim3(512), lds_bytes, s, wpack,
+                       reinterpret_cast<const bf16x8*>(X), reinterpret_cast<bf16x8*>(Y), P, n_tiles32);
+    HIP_TRY(hipGetLastError());
+    return prof_end(m, s, pi);
+}
+
+template <int NP>
+static int launch_gru_bf16_layer(cf_model* m, int l, bool last, const float* cur, float* y, float* p, int n_tiles32, hipStream_t s) {
+    const char* wp = m->d_gru_b[l];
+    if (l == 0)
+        return last ? launch_gru_bf16<32, true, NP>(m, wp, cur, y, p, n_tiles32, s, SLOT_GRU_LAST)
+                    : launch_gru_bf16<32, false, NP>(m, wp, cur, y, p, n_tiles32, s, SLOT_GRU0);
+    return last ? launch_gru_bf16<128, true, NP>(m, wp, cur, y, p, n_tiles32, s, SLOT_GRU_LAST)
+                : launch_gru_bf16<128, false, NP>(m, wp, cur, y, p, n_tiles32, s, SLOT_GRU);
+}
+
 static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_windows, float* probs, hipStream_t s) {
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    const int n_tiles32 = (int)((n_windows + 2 * CF_TILE - 1) / (2 * CF_TILE));
     int rc;
     size_t pi = 0;
     // residual blocks
@@ -701,12 +778,16 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         if (b == 0) {
             if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = (res_pack_floats(true) + 4 * CF_TILE * CF_T) * 4;
-            hipLaunchKernelGGL((res_block_kernel<true>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[0], x,
+            const bool lastb = m->hp.n_layers_res == 1;
+            auto kfn = (lastb && m->np == 1) ? res_block_kernel<true, 1> : (lastb && m->np == 2) ? res_block_kernel<true, 2> : res_block_kernel<true, 0>;
+            hipLaunchKernelGGL(kfn, dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[0], x,
                                (const f32x4*)nullptr, reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         } else {
             if ((rc = prof_begin(m, SLOT_RES, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = res_pack_floats(false) * 4;
-            hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
+            const bool lastb = b == m->hp.n_layers_res - 1;
+            auto kfn = (lastb && m->np == 1) ? res_block_kernel<false, 1> : (lastb && m->np == 2) ? res_block_kernel<false, 2> : res_block_kernel<false, 0>;
+            hipLaunchKernelGGL(kfn, dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
                                reinterpret_cast<const f32x4*>(sl.d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         }
         HIP_TRY(hipGetLastError());
@@ -717,7 +798,10 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     for (int l = 0; l < m->hp.n_layers; ++l) {
         const bool last = l == m->hp.n_layers - 1;
         float* y = sl.d_y[l & 1];
-        if (l == 0) {
+        if (m->np > 0) {
+            rc = m->np == 1 ? launch_gru_bf16_layer<1>(m, l, last, cur, y, sl.d_p, n_tiles32, s)
+                            : launch_gru_bf16_layer<2>(m, l, last, cur, y, sl.d_p, n_tiles32, s);
+        } else if (l == 0) {
             rc = last ? launch_gru<32, true>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU_LAST)
                       : launch_gru<32, false>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU0);
         } else {
@@ -730,7 +814,8 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     // head
     if ((rc = prof_begin(m, SLOT_HEAD, s, &pi)) != CF_OK) return rc;
     const int64_t total = n_windows * CF_T;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sl.d_p, m->dense_bias, probs, n_windows, n_tiles);
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sl.d_p, m->dense_bias, probs, n_windows,
+                       m->np > 0 ? n_tiles32 : n_tiles, m->np > 0 ? 5 : 4);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     sl.last_windows = n_windows;
@@ -864,6 +949,7 @@ extern "C" const char* cf_profile_slot_name(int slot) {
 // ---- debug hook --------------------------------------------------------------------------
 extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host) {
     if (!m || !out_host) return fail(CF_ERR_INVALID, "cf_debug_stage: null argument");
+    if (m->np > 0) return fail(CF_ERR_INVALID, "cf_debug_stage: only available with CF_PREC_FP32");
     const cf_model::Slot& sl = m->slots[0];
     if (n_windows <= 0 || n_windows > sl.last_windows) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds slot 0's last pass");
     HIP_TRY(hipSetDevice(m->device));
@@ -896,4 +982,4 @@ extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* 
 
 extern "C" int64_t cf_workspace_bytes(const cf_model* m) { return m ? m->ws_bytes : 0; }
 extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cf_version(void) { return "catfish_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+extern "C" const char* cf_version(void) { return "catfish_hip 0.2 (gfx950; fp32 MFMA 16x16x4, bf16 / bf16x3 MFMA 32x32x16)"; }

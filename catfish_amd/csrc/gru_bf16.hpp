@@ -1,0 +1,266 @@
+// gru_bf16.hpp -- biGRU layer on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), fp32 accumulate,
+// fp32 hidden state.  Included by catfish_hip.hip (shares its helpers).
+//
+// Two precisions, selected by NP (number of bf16 parts per operand):
+//   NP = 1  "bf16"   : operands rounded to bf16 (BASELINE config 4).
+//   NP = 2  "bf16x3" : every fp32 operand v is split as v ~ hi + lo (hi = bf16(v), lo = bf16(v - hi),
+//                      16-17 significant bits) and a*w is evaluated as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo
+//                      (3 MFMAs, fp32 accumulate): an fp32-emulating split that keeps the 1e-4 gate.
+//
+// Unlike v_mfma_f32_16x16x4_f32 (which serialises with the VALU), the bf16 MFMA runs on
+// the matrix pipe and co-executes with the sigmoid/tanh VALU work of the partner wave.
+//
+// Tile = 32 windows.  D[feature][window]: lane l holds window l&31 and rows
+// (reg&3) + 8*(reg>>2) + 4*(l>>5) of a 32-feature M-tile.  As in the fp32 kernels the accumulator
+// layout doubles as a B-operand layout under a permutation of k: registers 8b..8b+7 of M-tile m are
+// k-block 2m+b, whose element j of lane-half hh is feature 32m + 16b + 8(j>>2) + 4hh + (j&3).
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__host__ __device__ constexpr int frag_feature32(int kb, int hh, int j) {
+    return 32 * (kb >> 1) + 16 * (kb & 1) + 8 * (j >> 2) + 4 * hh + (j & 3);
+}
+
+// Packed blob of one direction (bytes): A fragments of 1 KiB ([lane][8 bf16]) in schedule order
+//   x part : [kb < CIN/16][mt < 6][part < NP]
+//   gates h: [kb < 4][mt < 4][part]
+//   cand  h: [kb < 4][mt < 2][part]     (M-tiles 4,5)
+// then fp32 bias [mt < 6][hh < 2][16] and fp32 dense weights [mt < 2][hh][16].
+__host__ __device__ constexpr int gb_seq(int cin) { return (cin / 16) * 6 + 16 + 8; }
+__host__ __device__ constexpr int gb_bias_off(int cin, int np) { return gb_seq(cin) * np * 1024; }
+__host__ __device__ constexpr int gb_dense_off(int cin, int np) { return gb_bias_off(cin, np) + 192 * 4; }
+__host__ __device__ constexpr int gb_pack_bytes(int cin, int np) { return gb_dense_off(cin, np) + 64 * 4; }
+
+// split 8 fp32 values into NP bf16 fragments (hi [, lo])
+template <int NP>
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[NP]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hi = (__bf16)v[j];
+        out[0][j] = hi;
+        if constexpr (NP == 2) out[1][j] = (__bf16)(v[j] - (float)hi);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ f32x16 prod(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16 c) {
+    c = MFMA32B(a[0], b[0], c);
+    if constexpr (NP == 2) {
+        c = MFMA32B(a[0], b[1], c);   // w_hi * a_lo
+        c = MFMA32B(a[1], b[0], c);   // w_lo * a_hi
+    }
+    return c;
+}
+
+// Activations between layers: [tile32][t][kb][part][lane][8 bf16]  (16 B per lane, 1 KiB per fragment)
+template <int CIN, bool LAST, int NP>
+__global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __restrict__ wpack,   // [2][gb_pack_bytes]
+                                                                const bf16x8* __restrict__ X,      // KBX k-blocks
+                                                                bf16x8* __restrict__ Y,            // 8 k-blocks
+                                                                float* __restrict__ P,             // [2][tile][t][32]
+                                                                int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KBX = CIN / 16;
+    constexpr int NX = KBX * 6, NG = 16, NC = 8, NSEQ = NX + NG + NC;
+    constexpr int PACK = gb_pack_bytes(CIN, NP);
+    constexpr int DA = 3;                          // A-fragment ring depth (schedule entries ahead)
+    constexpr int DX = (KBX >= 8 && NP == 2) ? KBX / 2 : KBX;   // x ring depth in k-blocks
+    static_assert(NSEQ % DA == 0 && KBX % DX == 0, "ring depths must divide the schedule");
+
+    const int dir = blockIdx.y;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < PACK / 16; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hh = lane >> 5;
+    const bf16x8* WA = reinterpret_cast<const bf16x8*>(lds) + lane;                     // + (p*NP + part)*64
+    const f32x4* BI = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_bias_off(CIN, NP)) + hh * 4;
+    const f32x4* DW = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_dense_off(CIN, NP)) + hh * 4;
+
+    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+        f32x16 h[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[m][i] = 0.f;                                 // GRUCellZeroState
+        bf16x8 hp[4][NP];                                                               // bf16 parts of h per k-block
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hp[kb][p][j] = (__bf16)0.f;
+
+        const int tstep = dir ? -1 : 1;                                                 // bw = reversed time
+        const int t0 = dir ? (CF_T - 1) : 0;
+        // x ring: k-block g of the whole 35-step sequence lives in slot g % DX
+        bf16x8 xr[DX][NP];
+        auto load_xblock = [&](int g, bf16x8 (&dst)[NP]) {
+            int s = g / KBX;
+            const int kb = g - s * KBX;
+            s = s > CF_T - 1 ? CF_T - 1 : s;                                            // past the end: harmless re-read
+            const int t = t0 + s * tstep;
+            const bf16x8* src = X + (((int64_t)tile * CF_T + t) * KBX + kb) * NP * 64 + lane;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[p] = src[p * 64];
+        };
+#pragma unroll
+        for (int g = 0; g < DX; ++g) load_xblock(g, xr[g]);
+        // A ring
+        bf16x8 ar[DA][NP];
+#pragma unroll
+        for (int q = 0; q < DA; ++q)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) ar[q][p] = WA[(q * NP + p) * 64];
+
+        for (int s = 0; s < CF_T; ++s) {
+            const int t = t0 + s * tstep;
+            f32x16 acc[6];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const f32x4 b = BI[mt * 8 + c4];
+                    acc[mt][4 * c4 + 0] = b.x; acc[mt][4 * c4 + 1] = b.y; acc[mt][4 * c4 + 2] = b.z; acc[mt][4 * c4 + 3] = b.w;
+                }
+            }
+            // one schedule entry: consume ring slot p % DA, refill it DA entries ahead
+#define CF_ENTRY(p, bparts, mt)                                                            \
+    {                                                                                      \
+        bf16x8 a_[NP];                                                                     \
+        _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) a_[pp] = ar[(p) % DA][pp];       \
+        _Pragma("unroll") for (int pp = 0; pp < NP; ++pp)                                  \
+            ar[(p) % DA][pp] = WA[((((p) + DA) % NSEQ) * NP + pp) * 64];                   \
+        acc[mt] = prod<NP>(a_, bparts, acc[mt]);                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+            // x part: [r | u | c] += Wx^T x_t
+#pragma unroll
+            for (int kb = 0; kb < KBX; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) CF_ENTRY(kb * 6 + mt, xr[kb % DX], mt);
+                load_xblock(s * KBX + kb + DX, xr[kb % DX]);
+            }
+            // gates, h part                                          (gru_cell/MatMul)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) CF_ENTRY(NX + kb * 4 + mt, hp[kb], mt);
+            }
+            // r = sigmoid(.), r*h -> bf16 parts (reset BEFORE the candidate matmul: gru_cell/mul -> concat_1)
+            bf16x8 rp[4][NP];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int m = kb >> 1, i = 8 * (kb & 1) + j;
+                    v[j] = cf_sigmoid(acc[m][i]) * h[m][i];
+                }
+                split8<NP>(v, rp[kb]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) CF_ENTRY(NX + NG + kb * 2 + mt, rp[kb], 4 + mt);
+            }
+#undef CF_ENTRY
+            // h' = u*h + (1-u)*c                                      (gru_cell/mul_1, sub, mul_2, add)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float u = cf_sigmoid(acc[2 + m][i]);
+                    const float c = cf_tanh(acc[4 + m][i]);
+                    h[m][i] = fmaf(u, h[m][i] - c, c);
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = h[kb >> 1][8 * (kb & 1) + j];
+                split8<NP>(v, hp[kb]);
+            }
+            if constexpr (!LAST) {
+                bf16x8* dst = Y + (((int64_t)tile * CF_T + t) * 8 + dir * 4) * NP * 64 + lane;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) dst[(kb * NP + p) * 64] = hp[kb][p];
+            } else {
+                // partial logit of this direction (final_fully_connected/MatMul), fp32 h
+                float pl = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const f32x4 wd = DW[m * 8 + c4];
+                        pl = fmaf(wd.x, h[m][4 * c4 + 0], pl); pl = fmaf(wd.y, h[m][4 * c4 + 1], pl);
+                        pl = fmaf(wd.z, h[m][4 * c4 + 2], pl); pl = fmaf(wd.w, h[m][4 * c4 + 3], pl);
+                    }
+                }
+                pl += __shfl_xor(pl, 32);
+                if (lane < 32) P[(((int64_t)dir * n_tiles + tile) * CF_T + t) * 32 + lane] = pl;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- host-side packing -------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);   // inf / nan: truncate
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+static void pack_gru_dir_bf16(const cf_gru_dir& g, int cin, int np, const float* dense_w, char* out) {
+    auto wfull = [&](int in, int o) -> float {
+        return o < 2 * CF_H ? g.gates_kernel[(size_t)in * 2 * CF_H + o] : g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)];
+    };
+    uint16_t* frag = reinterpret_cast<uint16_t*>(out);
+    int p = 0;
+    auto emit = [&](int in_base, int kb, int mt) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const float w = wfull(in_base + frag_feature32(kb, lane >> 5, j), 32 * mt + (lane & 31));
+                const uint16_t hi = f32_to_bf16_rne(w);
+                frag[((size_t)(p * np + 0) * 64 + lane) * 8 + j] = hi;
+                if (np == 2) frag[((size_t)(p * np + 1) * 64 + lane) * 8 + j] = f32_to_bf16_rne(w - bf16_to_f32(hi));
+            }
+        ++p;
+    };
+    for (int kb = 0; kb < cin / 16; ++kb) for (int mt = 0; mt < 6; ++mt) emit(0, kb, mt);
+    for (int kb = 0; kb < 4; ++kb) for (int mt = 0; mt < 4; ++mt) emit(cin, kb, mt);
+    for (int kb = 0; kb < 4; ++kb) for (int mt = 4; mt < 6; ++mt) emit(cin, kb, mt);
+    float* pb = reinterpret_cast<float*>(out + gb_bias_off(cin, np));
+    for (int mt = 0; mt < 6; ++mt)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int i = 0; i < 16; ++i) {
+                const int o = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                pb[(mt * 2 + hh) * 16 + i] = o < 2 * CF_H ? g.gates_bias[o] : g.candidate_bias[o - 2 * CF_H];
+            }
+    float* pd = reinterpret_cast<float*>(out + gb_dense_off(cin, np));
+    for (int m = 0; m < 2; ++m)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int i = 0; i < 16; ++i)
+                pd[(m * 2 + hh) * 16 + i] = dense_w ? dense_w[32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh] : 0.f;
+}

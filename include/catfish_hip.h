@@ -36,6 +36,12 @@ extern "C" {
 
 #define CF_WINDOW 35          /* rnn_class.py:27 (self.window) */
 
+/* Arithmetic of the biGRU layers (the residual blocks, the hidden state, the gates'
+ * sigmoid/tanh and all accumulation are fp32 in every mode). */
+#define CF_PREC_FP32 0        /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32); default            */
+#define CF_PREC_BF16X3 1      /* operands split hi+lo bf16, 3 bf16 MFMAs per product (~2^-17) */
+#define CF_PREC_BF16 2        /* operands rounded to bf16 (BASELINE config 4)                 */
+
 /* Hyper-parameters: the keys of ResNetRNN.txt parsed by
  * neural_network.retrieve_hyperparams (catfish/neural_network.py:37-67)
  * that shape the forward graph. */
@@ -49,6 +55,7 @@ typedef struct cf_hparams {
     int64_t max_windows_per_pass;/* scratch capacity per slot; longer inputs are chunked */
     int32_t n_streams;           /* scratch slots + internal streams that overlap the
                                     sub-batches of one call (0 = default 1 = none)       */
+    int32_t precision;           /* CF_PREC_*                                          */
 } cf_hparams;
 
 /* One conv1d + batch_normalization pair, TF layout

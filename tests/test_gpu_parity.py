@@ -72,3 +72,38 @@ def test_empty_and_bad_shapes(engine):
     assert engine.infer_host(np.zeros((0, 35), np.float32)).shape == (0,)
     with pytest.raises(ValueError):
         engine.infer_host(np.zeros((4, 34), np.float32))
+
+
+@pytest.mark.parametrize("precision,tol,min_match", [("bf16x3", 1e-4, 0.9995), ("bf16", 3e-2, 0.99)])
+def test_bf16_modes_on_golden_read(ckpt_weights, golden_read, precision, tol, min_match):
+    """bf16x3 (split-operand fp32 emulation) keeps the 1e-4 gate; plain bf16 (config 4) is judged by
+    label match rate and a loose probability bound."""
+    from catfish_amd.engine import HipEngine
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096, precision=precision)
+    try:
+        probs = eng.infer_host(golden_read["x"])
+    finally:
+        eng.close()
+    err = np.abs(probs.astype(np.float64) - golden_read["probs_fp64"]).max()
+    match = np.mean((probs >= 0.5) == (golden_read["probs_fp32"] >= 0.5))
+    print(precision, "max|dp|", err, "label match", match)
+    assert err < tol, err
+    assert match >= min_match, match
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("n_windows", [1, 31, 32, 33, 255, 257, 1000])
+def test_bf16_modes_ragged_random_weights(precision, tol, n_windows):
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=100 + n_windows)
+    rng = np.random.default_rng(n_windows)
+    x = rng.normal(0, 1.5, size=(n_windows, 35)).astype(np.float32)
+    eng = HipEngine(w, device=0, max_windows_per_pass=512, precision=precision)
+    try:
+        got = eng.infer_host(x)
+    finally:
+        eng.close()
+    want = oracle.forward(x, w, np.float64)
+    err = np.abs(got - want).max()
+    assert np.isfinite(got).all()
+    assert err < tol, err
