@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="scratch slots/internal streams per engine (0 = library default)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
                     help="arithmetic of the biGRU matmuls (fp32 = exact fp32 MFMA, the BASELINE configs[1] dtype)")
+    ap.add_argument("--no-extra-precisions", action="store_true",
+                    help="skip the short informational legs that time the other precisions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="disable per-kernel HIP events")
     args = ap.parse_args()
@@ -188,6 +190,29 @@ def main():
             "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match, "gate": 1e-4},
         }
         result["cpu_baseline"] = cpu_res
+    # informational legs: the same workload with the other GRU arithmetics (not the headline value)
+    if world == 1 and not args.no_extra_precisions:
+        extra = {}
+        for prec in ("fp32", "bf16x3", "bf16"):
+            if prec == args.precision:
+                continue
+            e2 = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, precision=prec)
+            for i in range(2):
+                e2.infer_device(batches[i % n_batches], out=outs[i & 1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n2 = max(5, args.steps // 2)
+            for i in range(n2):
+                e2.infer_device(batches[i % n_batches], out=outs[i & 1])
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t1
+            from oracle import catfish_oracle as oracle
+            got = e2.infer_device(batches[0], out=outs[0]).cpu().numpy()[:118 * WINDOW].astype(np.float64)
+            want = oracle.forward(reads[0], weights, np.float64)
+            extra[prec] = {"value": n2 * samples_per_step / d2, "unit": "samples/s", "ms_per_step": d2 / n2 * 1e3,
+                           "max_abs_dp_vs_fp64_oracle": float(np.abs(got - want).max())}
+            e2.close()
+        result["other_precisions"] = extra
     eng.close()
     if world > 1:
         dist.barrier()

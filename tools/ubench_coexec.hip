@@ -1,68 +1,134 @@
-// Microbenchmark: do f32 MFMA (v_mfma_f32_16x16x4_f32) and f32 VALU work from two waves on the
-// SAME SIMD overlap on gfx950?  Each workgroup has 8 waves (2 per SIMD); waves 0-3 run role A,
-// waves 4-7 role B.  Roles: 0 = idle, 1 = MFMA loop, 2 = VALU fma loop, 3 = transcendental loop.
+// Microbenchmark: how do MFMA and VALU/transcendental work share one SIMD on gfx950?
+// Each workgroup has 8 waves (2 per SIMD; waves w and w+4 share a SIMD); waves 0-3 run role A,
+// waves 4-7 role B.  100 KiB of dynamic LDS forces ONE workgroup per CU.
+// Roles: 0 idle | 1 f32 MFMA 16x16x4 | 2 VALU fma | 3 transcendental (exp2+rcp) | 4 bf16 MFMA 32x32x16
+//        5 one wave interleaving bf16 MFMA with 6 VALU fma each | 6 same with f32 MFMA
+//        7 one wave interleaving bf16 MFMA with 2 transcendentals + 2 fma each | 8 same with f32 MFMA
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(512, 2) void k(float* out, int roleA, int roleB, int iters) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave < 4 ? roleA : roleB;
-    float r = threadIdx.x * 1e-3f;
-    if (role == 1) {
+template <int ROLE>
+__device__ __forceinline__ float work(float r, int iters) {
+    if constexpr (ROLE == 1) {
         f32x4 acc[8];
         for (int i = 0; i < 8; ++i) acc[i] = (f32x4){r, r, r, r};
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(r, 1.0001f, acc[i], 0, 0, 0);
-            }
         }
         for (int i = 0; i < 8; ++i) r += acc[i].x + acc[i].y;
-    } else if (role == 2) {
+    } else if constexpr (ROLE == 2) {
         float a[16];
         for (int i = 0; i < 16; ++i) a[i] = r + i;
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 16; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
-            }
         }
         for (int i = 0; i < 16; ++i) r += a[i];
-    } else if (role == 3) {
+    } else if constexpr (ROLE == 3) {
         float a[16];
         for (int i = 0; i < 16; ++i) a[i] = r + i;
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a[i]));
-            }
         }
         for (int i = 0; i < 16; ++i) r += a[i];
+    } else if constexpr (ROLE == 4 || ROLE == 5 || ROLE == 7) {
+        f32x16 acc[4];
+        bf16x8 a, b;
+        float v[12];
+        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)r; b[j] = (__bf16)1.0f; }
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = r;
+        for (int i = 0; i < 12; ++i) v[i] = r + i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                    if constexpr (ROLE == 5) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) v[(i * 6 + q) % 12] = __builtin_fmaf(v[(i * 6 + q) % 12], 1.0001f, 0.5f);
+                    }
+                    if constexpr (ROLE == 7) {
+                        v[2 * i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[2 * i]));
+                        v[2 * i + 1] = __builtin_fmaf(v[2 * i + 1], 1.0001f, 0.5f);
+                        v[8 + i] = __builtin_fmaf(v[8 + i], 1.0001f, 0.5f);
+                    }
+                }
+        }
+        for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][5];
+        for (int i = 0; i < 12; ++i) r += v[i];
+    } else if constexpr (ROLE == 6 || ROLE == 8) {
+        f32x4 acc[8];
+        float v[12];
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){r, r, r, r};
+        for (int i = 0; i < 12; ++i) v[i] = r + i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(r, 1.0001f, acc[i], 0, 0, 0);
+                    if constexpr (ROLE == 6) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) v[(i * 6 + q) % 12] = __builtin_fmaf(v[(i * 6 + q) % 12], 1.0001f, 0.5f);
+                    }
+                    if constexpr (ROLE == 8) {
+                        v[i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[i]));
+                        v[8 + (i & 3)] = __builtin_fmaf(v[8 + (i & 3)], 1.0001f, 0.5f);
+                    }
+                }
+        }
+        for (int i = 0; i < 8; ++i) r += acc[i].x;
+        for (int i = 0; i < 12; ++i) r += v[i];
     }
+    return r;
+}
+
+template <int RA, int RB>
+__global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
+    extern __shared__ float pad[];
+    if (iters < 0) pad[threadIdx.x] = 1.f;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float r = threadIdx.x * 1e-3f;
+    if (wave < 4) r = work<RA>(r, iters);
+    else r = work<RB>(r, iters);
     out[blockIdx.x * 512 + threadIdx.x] = r;
+}
+
+static const char* names[] = {"idle", "f32mfma", "valu", "trans", "bf16mfma", "bf16mfma+6fma", "f32mfma+6fma", "bf16mfma+trans", "f32mfma+trans"};
+
+template <int RA, int RB>
+void run(float* d) {
+    const int iters = 4000;
+    hipFuncSetAttribute((const void*)k<RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<RA, RB>), dim3(256), dim3(512), 100 * 1024, 0, d, iters);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<RA, RB>), dim3(256), dim3(512), 100 * 1024, 0, d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("A=%-15s B=%-15s %.3f ms\n", names[RA], names[RB], ms);
 }
 
 int main() {
     float* d;
     hipMalloc(&d, 256 * 512 * 4);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 4000;
-    const char* names[] = {"idle", "mfma", "valu", "trans"};
-    int combos[][2] = {{1, 0}, {2, 0}, {3, 0}, {1, 1}, {2, 2}, {3, 3}, {1, 2}, {1, 3}, {2, 3}};
-    for (auto& c : combos) {
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, d, c[0], c[1], iters);
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, d, c[0], c[1], iters);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        // per-wave work: mfma: iters*32 MFMAs (32 cyc each); valu: iters*256 fma (4 cyc issue); trans: iters*128*2 ops (8 cyc)
-        printf("A=%-5s B=%-5s  %.3f ms\n", names[c[0]], names[c[1]], ms);
-    }
+    run<1, 0>(d); run<2, 0>(d); run<3, 0>(d); run<4, 0>(d);
+    run<1, 1>(d); run<2, 2>(d); run<3, 3>(d); run<4, 4>(d);
+    run<1, 2>(d); run<2, 1>(d); run<1, 3>(d); run<4, 2>(d); run<2, 4>(d); run<4, 3>(d); run<3, 4>(d);
+    run<5, 0>(d); run<6, 0>(d); run<7, 0>(d); run<8, 0>(d); run<5, 5>(d); run<7, 7>(d); run<8, 8>(d);
     return 0;
 }
