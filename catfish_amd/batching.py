@@ -129,3 +129,46 @@ def infer_reads(model, signals, max_windows=None, threshold=0.5, min_run=15):
         for i, res in zip(bucket, infer_packed(engine, packed, threshold, min_run)):
             out[i] = res
     return out
+
+
+def infer_reads_dac(model, dac_reads, max_windows=None, threshold=0.5, min_run=15, return_probs=False):
+    """Raw int16 DAC reads (leader already trimmed) -> [(spans, length)] with normalisation ON DEVICE.
+
+    Uploads 2 B per sample; median/MAD normalisation, padding and window packing run in
+    ``cf_normalize`` (bit-identical to infer.normalize_raw_signal cast to float32), then the
+    forward pass and the device post-processing as in ``infer_packed``.
+    """
+    import torch
+    engine = model.engine if hasattr(model, "engine") else model
+    if engine is None:
+        raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
+    dac_reads = [np.ascontiguousarray(np.asarray(r).reshape(-1), dtype=np.int16) for r in dac_reads]
+    if max_windows is None:
+        max_windows = 32768
+    dev = torch.device("cuda", engine.device)
+    out = [None] * len(dac_reads)
+    probs_out = [None] * len(dac_reads)
+    for bucket in length_buckets([len(r) for r in dac_reads], max_windows):
+        lengths = np.array([len(dac_reads[i]) for i in bucket], dtype=np.int64)
+        dac_off = np.zeros(len(bucket) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=dac_off[1:])
+        n_win = np.array([(int(n) + padding_size_for(int(n))) // WINDOW_SIZE for n in lengths], dtype=np.int64)
+        win_off = np.zeros(len(bucket) + 1, dtype=np.int64)
+        np.cumsum(n_win, out=win_off[1:])
+        flat = np.concatenate([dac_reads[i] for i in bucket]) if len(bucket) else np.zeros(0, np.int16)
+        d_dac = torch.from_numpy(flat).to(dev)
+        d_doff = torch.from_numpy(dac_off).to(dev)
+        d_woff = torch.from_numpy(win_off).to(dev)
+        x = torch.empty(int(win_off[-1]), WINDOW_SIZE, dtype=torch.float32, device=dev)
+        engine.normalize_device(d_dac, d_doff, d_woff, out=x)
+        probs = engine.infer_device(x)
+        s_off = win_off * WINDOW_SIZE
+        labels = engine.postprocess_device(probs, torch.from_numpy(s_off).to(dev), torch.from_numpy(lengths).to(dev),
+                                           threshold=threshold, min_run=min_run)
+        spans = spans_from_labels(labels.cpu().numpy(), s_off, len(bucket))
+        p_host = probs.cpu().numpy() if return_probs else None
+        for k, i in enumerate(bucket):
+            out[i] = (spans[k], int(lengths[k]))
+            if return_probs:
+                probs_out[i] = p_host[s_off[k]:s_off[k] + lengths[k]]
+    return (out, probs_out) if return_probs else out

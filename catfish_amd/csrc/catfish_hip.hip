@@ -430,6 +430,87 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
     labels[i] = out;
 }
 
+// ------------------------------------------------------------------------------------------
+// Kernel 5: signal ingest -- per-read median / MAD normalisation of raw int16 DAC samples
+// (normalize_raw_signal, infer.py:96-105) fused with the zero padding + window packing of
+// infer.py:31-43.  One workgroup per read.  Medians are found exactly by radix selection over
+// LDS histograms (int16 keys: 8 + 8 bits; doubled absolute deviations, 17 bits: 9 + 8 bits); for
+// even lengths the two middle order statistics are averaged like numpy.median.  The division is
+// done in double and rounded once to fp32, i.e. bit-identical to numpy's float64 result cast to
+// float32 (what TF's feed does, rnn_class.py:214).
+// ------------------------------------------------------------------------------------------
+template <typename KeyFn>
+__device__ int radix_select(const int16_t* __restrict__ v, int64_t n, int64_t rank, int hi_bits, KeyFn key, unsigned* hist,
+                            unsigned* sh) {
+    // level 1: histogram of the high bits
+    const int nb1 = 1 << hi_bits;
+    for (int i = threadIdx.x; i < nb1; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[key(v[i]) >> 8], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t acc = 0;
+        int b = 0;
+        for (; b < nb1; ++b) {
+            if (acc + hist[b] > rank) break;
+            acc += hist[b];
+        }
+        sh[0] = (unsigned)b;
+        sh[1] = (unsigned)(rank - acc);     // rank inside the bin
+    }
+    __syncthreads();
+    const unsigned bin = sh[0];
+    const unsigned r2 = sh[1];
+    __syncthreads();
+    // level 2: histogram of the low 8 bits inside that bin
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned k = key(v[i]);
+        if ((k >> 8) == bin) atomicAdd(&hist[k & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned acc = 0;
+        int b = 0;
+        for (; b < 256; ++b) {
+            if (acc + hist[b] > r2) break;
+            acc += hist[b];
+        }
+        sh[2] = (bin << 8) | (unsigned)b;
+    }
+    __syncthreads();
+    const int out = (int)sh[2];
+    __syncthreads();
+    return out;
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(const int16_t* __restrict__ dac, const int64_t* __restrict__ dac_offsets,
+                                                        const int64_t* __restrict__ win_offsets, float* __restrict__ x_out) {
+    __shared__ unsigned hist[512];
+    __shared__ unsigned sh[4];
+    const int64_t r = blockIdx.x;
+    const int16_t* v = dac + dac_offsets[r];
+    const int64_t n = dac_offsets[r + 1] - dac_offsets[r];
+    float* out = x_out + win_offsets[r] * CF_T;
+    const int64_t n_pad = (win_offsets[r + 1] - win_offsets[r]) * CF_T;
+    if (n <= 0) {
+        for (int64_t i = threadIdx.x; i < n_pad; i += blockDim.x) out[i] = 0.f;
+        return;
+    }
+    auto key16 = [](int16_t x) -> unsigned { return (unsigned)((int)x + 32768); };
+    const int lo = radix_select(v, n, (n - 1) / 2, 8, key16, hist, sh);
+    const int hi = (n & 1) ? lo : radix_select(v, n, n / 2, 8, key16, hist, sh);
+    const int med2 = (lo - 32768) + (hi - 32768);            // 2 * median, exact
+    auto keydev = [med2](int16_t x) -> unsigned { const int d = 2 * (int)x - med2; return (unsigned)(d < 0 ? -d : d); };
+    const int dlo = radix_select(v, n, (n - 1) / 2, 9, keydev, hist, sh);
+    const int dhi = (n & 1) ? dlo : radix_select(v, n, n / 2, 9, keydev, hist, sh);
+    const double shift = 0.5 * (double)med2;
+    const double scale = 0.25 * (double)(dlo + dhi);          // median(|raw - shift|)
+    for (int64_t i = threadIdx.x; i < n_pad; i += blockDim.x)
+        out[i] = i < n ? (float)(((double)v[i] - shift) / scale) : 0.f;
+}
+
 // ==========================================================================================
 // Host side
 // ==========================================================================================
@@ -446,9 +527,9 @@ static int fail(int code, const std::string& msg) {
             return fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
-enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_UNUSED };
+enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_NORM };
 static const char* k_slot_names[CF_PROF_SLOTS] = {"res_block_first", "res_block",      "gru_layer_first", "gru_layer_mid",
-                                                  "gru_layer_last",  "head",           "postprocess",     "unused"};
+                                                  "gru_layer_last",  "head",           "postprocess",     "normalize"};
 
 struct cf_model {
     cf_hparams hp;
@@ -903,6 +984,23 @@ extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* re
     if (rc != CF_OK) return rc;
     hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, probs, read_offsets,
                        read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
+    HIP_TRY(hipGetLastError());
+    return prof_end(m, s, pi);
+}
+
+extern "C" int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets, const int64_t* win_offsets,
+                            int64_t n_reads, float* x_out, void* stream) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_normalize: null model");
+    if (n_reads < 0) return fail(CF_ERR_INVALID, "cf_normalize: negative n_reads");
+    if (n_reads == 0) return CF_OK;
+    if (!dac || !dac_offsets || !win_offsets || !x_out) return fail(CF_ERR_INVALID, "cf_normalize: null buffer");
+    if (n_reads > 0x7FFFFFFF) return fail(CF_ERR_INVALID, "cf_normalize: too many reads in one call");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    size_t pi = 0;
+    int rc = prof_begin(m, SLOT_NORM, s, &pi);
+    if (rc != CF_OK) return rc;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)n_reads), dim3(256), 0, s, dac, dac_offsets, win_offsets, x_out);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
 }

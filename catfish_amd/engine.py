@@ -118,6 +118,30 @@ class HipEngine(object):
                                          C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream)))
         return out
 
+    def normalize_device(self, dac, dac_offsets, win_offsets, out=None, stream=None):
+        """Device median/MAD normalisation + padding + window packing of many int16 reads.
+
+        dac: int16 CUDA [total samples]; dac_offsets / win_offsets: int64 CUDA [n_reads + 1]
+        -> float32 CUDA [n_windows, 35] (n_windows = win_offsets[-1], given by ``out`` or computed).
+        """
+        import torch
+        if dac.dtype != torch.int16 or not dac.is_cuda or not dac.is_contiguous():
+            raise ValueError("dac must be a contiguous int16 CUDA tensor")
+        for t in (dac_offsets, win_offsets):
+            if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("offset tables must be contiguous int64 CUDA tensors")
+        n_reads = int(dac_offsets.numel()) - 1
+        if int(win_offsets.numel()) != n_reads + 1:
+            raise ValueError("dac_offsets and win_offsets must have the same length")
+        if out is None:
+            out = torch.empty(int(win_offsets[-1].item()), WINDOW, dtype=torch.float32, device=dac.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(dac.device)
+        N.check(self._lib.cf_normalize(self._handle, C.c_void_p(dac.data_ptr()), C.c_void_p(dac_offsets.data_ptr()),
+                                       C.c_void_p(win_offsets.data_ptr()), n_reads, C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(stream.cuda_stream)))
+        return out
+
     # ------------------------------------------------------------------ profiling / debug
     def profile_enable(self, on=True):
         N.check(self._lib.cf_profile_enable(self._handle, 1 if on else 0))

@@ -122,6 +122,17 @@ int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets,
                    const int64_t* read_lengths, int64_t n_reads, int64_t total_samples,
                    float threshold, int32_t min_run, uint8_t* labels, void* stream);
 
+/* Signal ingest on device, replacing normalize_raw_signal + the padding / reshape of
+ * infer_class_from_signal (catfish/infer.py:96-105, 31-43) for many reads at once.
+ * dac: device int16, the reads' raw DAC samples back to back (after the leader trim of
+ * process_signal, infer.py:87-90); dac_offsets: device int64[n_reads + 1] sample offsets into
+ * dac; win_offsets: device int64[n_reads + 1] first window of every read in the packed output;
+ * x_out: device fp32 [win_offsets[n_reads], 35], receives (raw - median) / median(|raw - median|)
+ * followed by each read's zero padding.  Results are bit-identical to numpy's float64
+ * normalisation cast to float32. */
+int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets,
+                 const int64_t* win_offsets, int64_t n_reads, float* x_out, void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, 1) makes every cf_infer record
  * events around each kernel; cf_profile_read synchronises and returns, for

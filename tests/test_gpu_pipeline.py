@@ -143,3 +143,36 @@ def test_extreme_inputs_saturate_cleanly(model):
         w = {k: z[k] for k in z.files}
     want = oracle.forward(x, w, np.float64)
     assert np.abs(out - want).max() < 1e-4
+
+
+def test_device_normalisation_is_bit_exact(model):
+    """cf_normalize vs numpy float64 normalisation cast to float32 (infer.py:96-105), incl. padding."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd import batching, infer
+    rng = np.random.default_rng(4)
+    lens = [1, 2, 3, 34, 35, 36, 70, 999, 4096, 10001]
+    reads = [np.clip(np.rint(rng.normal(500, 60, size=n)), 0, 2047).astype(np.int16) for n in lens]
+    reads.append(rng.integers(-32768, 32767, size=777).astype(np.int16))      # full int16 range
+    reads.append(np.array([5, 5, 5, 9, 1, 5, 5, 5, 5, 7], dtype=np.int16))     # many ties
+    lens = [len(r) for r in reads]
+    dev = torch.device("cuda", 0)
+    dac_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    n_win = [(n + infer.padding_size_for(n)) // 35 for n in lens]
+    win_off = np.concatenate(([0], np.cumsum(n_win))).astype(np.int64)
+    x = model.engine.normalize_device(torch.from_numpy(np.concatenate(reads)).to(dev),
+                                      torch.from_numpy(dac_off).to(dev), torch.from_numpy(win_off).to(dev)).cpu().numpy()
+    for i, r in enumerate(reads):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = infer.normalize_raw_signal(r, "median").astype(np.float32)
+        got = x[win_off[i]:win_off[i + 1]].reshape(-1)
+        assert np.array_equal(got[:lens[i]], want, equal_nan=True), i
+        assert np.all(got[lens[i]:] == 0), i
+
+
+def test_dac_pipeline_matches_oracle(model, ckpt_weights):
+    from catfish_amd import batching
+    dacs = [oracle.synthetic_dac(1, n, seed=40 + n)[0] for n in (512, 4096, 700, 9000)]
+    got = batching.infer_reads_dac(model, dacs, max_windows=2048)
+    for d, g in zip(dacs, got):
+        w_spans, w_len, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
+        assert g == (w_spans, w_len)
