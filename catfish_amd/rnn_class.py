@@ -47,6 +47,10 @@ class RNN(object):
 
         self.weights = None
         self.engine = None
+        self._trainer = None
+        self._engine_stale = False
+        self.train_loss = None
+        self.train_seed = kwargs.get("train_seed")
         if save:
             raise NotImplementedError("save=True (TensorBoard/model directory bookkeeping, rnn_class.py:43-46) "
                                       "belongs to the training stack, which is out of scope of this path")
@@ -75,6 +79,8 @@ class RNN(object):
         if self.engine is not None:
             self.engine.close()
         self.weights = weights
+        self._trainer = None
+        self._engine_stale = False
         self.engine = HipEngine(weights, layer_size=self.layer_size, n_layers=self.n_layers,
                                 layer_size_res=self.layer_size_res_, n_layers_res=self.n_layers_res_,
                                 device=self.device, max_windows_per_pass=self.max_windows_per_pass)
@@ -138,6 +144,12 @@ class RNN(object):
     def _require_engine(self):
         if self.engine is None:
             raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
+        if self._engine_stale:
+            # weights moved by train_network: re-tile them into the HIP engine
+            trainer = self._trainer
+            self._load_engine(trainer.net.numpy_weights())
+            self._trainer = trainer
+            self._engine_stale = False
 
     def infer(self, input_x):
         """rnn_class.py:213-219: [N,35,1] -> float64 confidences, flattened [N*35]."""
@@ -173,8 +185,20 @@ class RNN(object):
         return test_acc, test_loss
 
     def train_network(self, train_x, train_y, step):
-        raise NotImplementedError("training (rnn_class.py:201-210) is a 'next' row of the scope table; "
-                                  "this build implements the inference path")
+        """rnn_class.py:201-210: one optimizer step on a batch (PyTorch-ROCm autograd, TF update rules).
+
+        The forward/backward of the training step runs in torch (BASELINE config 5: "Adam in
+        PyTorch-ROCm"); the updated weights are pushed back into the HIP engine lazily, at the
+        next ``infer``.  TensorBoard summaries (the reference's second forward) are not written.
+        """
+        if self.weights is None:
+            raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
+        if self._trainer is None:
+            from .training import Trainer
+            self._trainer = Trainer(self.weights, self.n_layers, self.n_layers_res_, self.optimizer_choice,
+                                    self.learning_rate, self.keep_prob, seed=self.train_seed)
+        self.train_loss = self._trainer.train_step(train_x, train_y)
+        self._engine_stale = True
 
     def save_info(self):
         raise NotImplementedError("save_info (rnn_class.py:264-270) belongs to the training stack")

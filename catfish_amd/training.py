@@ -1,0 +1,170 @@
+"""Training step (BASELINE config 5) -- the reference's ``train_network`` on PyTorch-ROCm autograd.
+
+Reference: ``RNN.train_network`` (catfish/models/rnn_class.py:201-210) runs one
+``optimizer.minimize(loss)`` step; loss = mean sigmoid cross-entropy over all B*35 outputs
+(:74-79); optimizer = Adam or RMSProp with TF-1 defaults (:62-71); dropout with
+``keep_prob`` on the GRU OUTPUTS only (:151-154); batch-norm stays in inference mode while
+training (``training`` is never passed, resnet_class.py:61) so only gamma/beta learn and the
+moving statistics never move.
+
+The graph is restated with torch ops in the TF variable layout (same names/shapes as the
+checkpoint), so trained weights go straight back into the HIP engine or a checkpoint-V2 bundle
+(``checkpoint.write_checkpoint``).  The optimizer updates follow TF's formulas, not torch.optim's
+(epsilon placement and slot initialisation differ).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _names(n_layers, n_layers_res):
+    conv = lambda j: "conv1d" if j == 0 else "conv1d_%d" % j            # noqa: E731
+    bn = lambda j: "batch_normalization" if j == 0 else "batch_normalization_%d" % j   # noqa: E731
+    return conv, bn
+
+
+class TorchResNetRNN(object):
+    """Differentiable restatement of the ResNetRNN graph; parameters are a dict of torch tensors."""
+
+    def __init__(self, weights, n_layers, n_layers_res, device="cpu", dtype=None):
+        import torch
+        self.torch = torch
+        self.dtype = dtype or torch.float32
+        self.device = torch.device(device)
+        self.n_layers = int(n_layers)
+        self.n_layers_res = int(n_layers_res)
+        self.params = {}
+        for k, v in weights.items():
+            t = torch.tensor(np.asarray(v), dtype=self.dtype, device=self.device)
+            t.requires_grad_(not k.endswith(("moving_mean", "moving_variance")))
+            self.params[k] = t
+
+    def trainable(self):
+        return {k: v for k, v in self.params.items() if v.requires_grad}
+
+    def numpy_weights(self):
+        return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in self.params.items()}
+
+    # ---- forward ---------------------------------------------------------------------------
+    def _conv_bn(self, x, j):
+        torch = self.torch
+        F = torch.nn.functional
+        conv, bn = _names(self.n_layers, self.n_layers_res)
+        p = self.params
+        k = p[conv(j) + "/kernel"]                       # [K, Cin, Cout]
+        y = F.conv1d(x, k.permute(2, 1, 0), p[conv(j) + "/bias"], padding=(k.shape[0] - 1) // 2)
+        inv = p[bn(j) + "/gamma"] * torch.rsqrt(p[bn(j) + "/moving_variance"] + 1e-3)
+        return y * inv[None, :, None] + (p[bn(j) + "/beta"] - p[bn(j) + "/moving_mean"] * inv)[None, :, None]
+
+    def logits(self, x, keep_prob=1.0, generator=None):
+        """x [N, 35] or [N, 35, 1] -> logits [N, 35]."""
+        torch = self.torch
+        p = self.params
+        x = torch.as_tensor(x, dtype=self.dtype, device=self.device)
+        if x.dim() == 3:
+            x = x[:, :, 0]
+        a = x[:, None, :]                                # [N, C, T]
+        for d in range(self.n_layers_res):
+            j0 = 4 * d
+            sc = self._conv_bn(a, j0)
+            o = torch.relu(self._conv_bn(a, j0 + 1))
+            o = torch.relu(self._conv_bn(o, j0 + 2))
+            o = torch.relu(self._conv_bn(o, j0 + 3))
+            a = torch.relu(o + sc)
+        a = a.permute(0, 2, 1)                           # [N, T, C]
+        n, t_len, _ = a.shape
+        for layer in range(self.n_layers):
+            outs = []
+            for dname, rev in (("fw", False), ("bw", True)):
+                pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell" % (layer, dname)
+                wg, bg = p[pre + "/gates/kernel"], p[pre + "/gates/bias"]
+                wc, bc = p[pre + "/candidate/kernel"], p[pre + "/candidate/bias"]
+                hsz = wc.shape[1]
+                h = torch.zeros(n, hsz, dtype=self.dtype, device=self.device)
+                seq = [None] * t_len
+                for s in (range(t_len - 1, -1, -1) if rev else range(t_len)):
+                    xt = a[:, s, :]
+                    g = torch.sigmoid(torch.cat([xt, h], 1) @ wg + bg)
+                    r, u = g[:, :hsz], g[:, hsz:]
+                    c = torch.tanh(torch.cat([xt, r * h], 1) @ wc + bc)
+                    h = u * h + (1 - u) * c
+                    seq[s] = h
+                out = torch.stack(seq, 1)
+                if keep_prob < 1.0:                      # DropoutWrapper(output_keep_prob): outputs only
+                    mask = torch.floor(keep_prob + torch.rand(out.shape, generator=generator, device=self.device,
+                                                              dtype=self.dtype))
+                    out = out / keep_prob * mask
+                outs.append(out)
+            a = torch.cat(outs, 2)
+        return (a.reshape(-1, a.shape[2]) @ p["final_fully_connected/kernel"] +
+                p["final_fully_connected/bias"]).reshape(n, t_len)
+
+    def loss(self, x, y, keep_prob=1.0, generator=None):
+        """tf.losses.sigmoid_cross_entropy + reduce_mean (rnn_class.py:74-79)."""
+        torch = self.torch
+        z = self.logits(x, keep_prob, generator)
+        y = torch.as_tensor(y, dtype=self.dtype, device=self.device).reshape(z.shape)
+        return torch.nn.functional.binary_cross_entropy_with_logits(z, y, reduction="mean")
+
+
+class TFOptimizer(object):
+    """tf.train.AdamOptimizer / RMSPropOptimizer update rules with TF-1 defaults (rnn_class.py:62-71)."""
+
+    def __init__(self, params, choice, lr):
+        import torch
+        self.torch = torch
+        if choice not in ("Adam", "RMSProp"):
+            raise ValueError("Given optimizer choice is not known. Choose 'Adam' or 'RMSProp'.")
+        self.choice = choice
+        self.lr = float(lr)
+        self.params = params
+        self.t = 0
+        if choice == "Adam":
+            self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+            self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        else:
+            self.ms = {k: torch.ones_like(v) for k, v in params.items()}      # TF initialises the rms slot to 1
+            self.mom = {k: torch.zeros_like(v) for k, v in params.items()}
+
+    def step(self):
+        torch = self.torch
+        self.t += 1
+        with torch.no_grad():
+            for k, p in self.params.items():
+                g = p.grad
+                if g is None:
+                    continue
+                if self.choice == "Adam":
+                    b1, b2, eps = 0.9, 0.999, 1e-8
+                    self.m[k].mul_(b1).add_(g, alpha=1 - b1)
+                    self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+                    lr_t = self.lr * np.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t)
+                    p.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + eps))
+                else:
+                    decay, eps = 0.9, 1e-10
+                    self.ms[k].mul_(decay).addcmul_(g, g, value=1 - decay)
+                    p.sub_(self.lr * g / torch.sqrt(self.ms[k] + eps))         # momentum = 0
+                p.grad = None
+
+
+class Trainer(object):
+    def __init__(self, weights, n_layers, n_layers_res, optimizer_choice, learning_rate, keep_prob, device=None,
+                 seed=None):
+        import torch
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.net = TorchResNetRNN(weights, n_layers, n_layers_res, device=device)
+        self.opt = TFOptimizer(self.net.trainable(), optimizer_choice, learning_rate)
+        self.keep_prob = float(keep_prob)
+        self.gen = torch.Generator(device=self.net.device)
+        if seed is not None:
+            self.gen.manual_seed(int(seed))
+        self.last_loss = None
+
+    def train_step(self, x, y, keep_prob=None):
+        kp = self.keep_prob if keep_prob is None else keep_prob
+        loss = self.net.loss(x, y, kp, self.gen)
+        loss.backward()
+        self.opt.step()
+        self.last_loss = float(loss.detach())
+        return self.last_loss

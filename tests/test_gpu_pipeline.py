@@ -176,3 +176,24 @@ def test_dac_pipeline_matches_oracle(model, ckpt_weights):
     for d, g in zip(dacs, got):
         w_spans, w_len, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
         assert g == (w_spans, w_len)
+
+
+def test_train_network_then_infer_uses_updated_weights(hp):
+    """Config 5 surface: train_network (torch-ROCm autograd, Adam) then infer through the HIP engine."""
+    pytest.importorskip("torch")
+    from catfish_amd.resnet_class import ResNetRNN
+    m = ResNetRNN(**dict(hp, optimizer_choice="Adam", train_seed=0))
+    m.set_weights(oracle.random_weights(seed=9))
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 1.2, size=(256, 35, 1)).astype(np.float32)
+    y = np.repeat((np.arange(256) % 2)[:, None], 35, axis=1).astype(np.float32)[:, :, None]
+    before = m.infer(x[:32])
+    losses = []
+    for step in range(3):
+        m.train_network(x, y, step)
+        losses.append(m.train_loss)
+    after = m.infer(x[:32])                       # engine re-tiled from the trained weights
+    assert np.isfinite(losses).all() and not np.allclose(before, after)
+    want = oracle.forward(x[:32], m._trainer.net.numpy_weights(), np.float64)
+    assert np.abs(after - want).max() < 1e-4
+    m.engine.close()

@@ -1,0 +1,98 @@
+"""Config 5 (train step) on CPU: the torch restatement matches the oracle's forward, its gradients
+match finite differences, and the TF-style optimizers follow their update formulas."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from catfish_amd.training import TorchResNetRNN, TFOptimizer, Trainer
+from oracle import catfish_oracle as oracle
+
+
+def _batch(n=8, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 1.2, size=(n, 35)).astype(np.float32)
+    y = np.repeat((np.arange(n) % 2)[:, None], 35, axis=1).astype(np.float32)   # uniform label per window
+    return x, y
+
+
+def test_torch_forward_matches_oracle(ckpt_weights):
+    x, _ = _batch(6)
+    net = TorchResNetRNN(ckpt_weights, 3, 2, dtype=torch.float64)
+    with torch.no_grad():
+        p = torch.sigmoid(net.logits(x)).numpy().reshape(-1)
+    want = oracle.forward(x, ckpt_weights, np.float64)
+    assert np.abs(p - want).max() < 1e-10
+
+
+def test_loss_is_mean_sigmoid_cross_entropy(ckpt_weights):
+    x, y = _batch(4)
+    net = TorchResNetRNN(ckpt_weights, 3, 2, dtype=torch.float64)
+    _, st = oracle.forward(x, ckpt_weights, np.float64, return_stages=True)
+    z = st["logits"].reshape(4, 35)
+    want = np.mean(np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z))))
+    assert abs(float(net.loss(x, y)) - want) < 1e-10
+
+
+def test_gradients_match_finite_differences():
+    w = oracle.random_weights(seed=5, n_layers=1, n_layers_res=1)
+    x, y = _batch(3, seed=1)
+    net = TorchResNetRNN(w, 1, 1, dtype=torch.float64)
+    loss = net.loss(x, y)
+    loss.backward()
+    rng = np.random.default_rng(0)
+    for name in ("conv1d_2/kernel", "batch_normalization_1/gamma",
+                 "stack_bidirectional_rnn/cell_0/bidirectional_rnn/bw/gru_cell/candidate/kernel",
+                 "final_fully_connected/bias"):
+        p = net.params[name]
+        idx = tuple(int(rng.integers(0, s)) for s in p.shape)
+        eps = 1e-6
+        with torch.no_grad():
+            p[idx] += eps
+            lp = float(net.loss(x, y))
+            p[idx] -= 2 * eps
+            lm = float(net.loss(x, y))
+            p[idx] += eps
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - float(p.grad[idx])) < 1e-6 * max(1.0, abs(fd)), name
+    assert net.params["batch_normalization/moving_mean"].grad is None      # BN statistics do not train
+
+
+@pytest.mark.parametrize("choice", ["Adam", "RMSProp"])
+def test_tf_optimizer_formulas(choice):
+    p = {"w": torch.tensor([1.0, -2.0], dtype=torch.float64, requires_grad=True)}
+    opt = TFOptimizer(p, choice, 0.1)
+    w = np.array([1.0, -2.0]); m = np.zeros(2); v = np.zeros(2); ms = np.ones(2)
+    for t in range(1, 4):
+        g = np.array([0.5 * t, -1.0])
+        p["w"].grad = torch.tensor(g)
+        opt.step()
+        if choice == "Adam":
+            m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+            w = w - 0.1 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-8)
+        else:
+            ms = 0.9 * ms + 0.1 * g * g
+            w = w - 0.1 * g / np.sqrt(ms + 1e-10)
+        assert np.allclose(p["w"].detach().numpy(), w, atol=1e-12)
+    with pytest.raises(ValueError):
+        TFOptimizer(p, "SGD", 0.1)
+
+
+def test_training_reduces_loss_and_keeps_shapes():
+    w = oracle.random_weights(seed=2)
+    x, y = _batch(16, seed=3)
+    tr = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
+    losses = [tr.train_step(x, y) for _ in range(12)]
+    assert losses[-1] < losses[0] - 1e-3, losses
+    nw = tr.net.numpy_weights()
+    assert sorted(nw) == sorted(w) and all(nw[k].shape == np.asarray(w[k]).shape for k in w)
+    assert np.array_equal(nw["batch_normalization/moving_variance"], w["batch_normalization/moving_variance"])
+
+
+def test_dropout_only_on_outputs_is_seeded():
+    w = oracle.random_weights(seed=2, n_layers=1, n_layers_res=1)
+    x, y = _batch(4)
+    a = Trainer(w, 1, 1, "RMSProp", 1e-3, keep_prob=0.8, device="cpu", seed=7).train_step(x, y)
+    b = Trainer(w, 1, 1, "RMSProp", 1e-3, keep_prob=0.8, device="cpu", seed=7).train_step(x, y)
+    c = Trainer(w, 1, 1, "RMSProp", 1e-3, keep_prob=1.0, device="cpu", seed=7).train_step(x, y)
+    assert a == b and a != c

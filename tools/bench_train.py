@@ -1,0 +1,51 @@
+"""BASELINE config 5: train step (forward + backward + Adam) on PyTorch-ROCm, windows/s.
+
+Synthetic config-2 windows, per-window uniform labels, 128 positive + 128 negative per batch of
+256 (mimics ExampleDb.get_training_set, networks/trainingDB/ExampleDb.py:50-83), keep_prob 0.8,
+lr 1e-3.  Also prints the 10-step loss trajectory next to a CPU run with dropout off.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from catfish_amd.training import Trainer  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    w = bench.load_weights()
+    reads = bench.make_reads(8, seed=5).reshape(-1, 35)
+    rng = np.random.default_rng(0)
+    x = reads[rng.permutation(len(reads))[:256]]
+    y = np.repeat((np.arange(256) % 2)[:, None], 35, axis=1).astype(np.float32)
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    gpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)
+    cpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
+    lg = [gpu.train_step(x, y) for _ in range(10)]
+    lc = [cpu.train_step(x, y) for _ in range(10)]
+    tr = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=0.8, device=dev, seed=0)
+    for _ in range(3):
+        tr.train_step(x, y)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        tr.train_step(x, y)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "training windows/s (config 5, torch autograd + TF-style Adam)", "device": dev,
+                      "value": n * 256 / dt, "ms_per_step": dt / n * 1e3,
+                      "loss_10_steps_device": lg, "loss_10_steps_cpu": lc,
+                      "max_loss_diff": float(np.max(np.abs(np.array(lg) - np.array(lc))))}))
+
+
+if __name__ == "__main__":
+    main()
