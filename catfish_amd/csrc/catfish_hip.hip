@@ -58,6 +58,17 @@ __device__ __forceinline__ float cf_tanh(float x) {
     // tanh(x) = 1 - 2 / (1 + exp(2x)); absolute error ~1e-7
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f);
 }
+// The GRU packers pre-scale the gate weights/biases by -log2(e) and the candidate's by 2*log2(e), so
+// the MFMA accumulators already hold the exp2 arguments (saves one v_mul per gate element):
+//   sigmoid(x) = 1 / (1 + 2^(-x log2 e)),   tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)).
+#define CF_GATE_SCALE (-1.4426950408889634)
+#define CF_CAND_SCALE (2.8853900817779268)
+__device__ __forceinline__ float cf_sigmoid_pre(float a) {   // a = -x * log2(e)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
+}
+__device__ __forceinline__ float cf_tanh_pre(float a) {      // a = 2 * x * log2(e)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)), 1.0f);
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     f32x4 o;
     o.x = fmaxf(v.x, 0.f); o.y = fmaxf(v.y, 0.f); o.z = fmaxf(v.z, 0.f); o.w = fmaxf(v.w, 0.f);
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rh[m][r] = (CF_ABLATE & 1) ? acc[m][r] * 0.001f : cf_sigmoid(acc[m][r]) * h[m][r];
+                for (int r = 0; r < 4; ++r) rh[m][r] = (CF_ABLATE & 1) ? acc[m][r] * 0.001f : cf_sigmoid_pre(acc[m][r]) * h[m][r];
             }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
@@ -351,8 +362,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (CF_ABLATE & 1) { h[m][r] = acc[4 + m][r] * 0.001f + acc[8 + m][r] * 0.001f; continue; }
-                    const float u = cf_sigmoid(acc[4 + m][r]);
-                    const float c = cf_tanh(acc[8 + m][r]);
+                    const float u = cf_sigmoid_pre(acc[4 + m][r]);
+                    const float c = cf_tanh_pre(acc[8 + m][r]);
                     h[m][r] = fmaf(u, h[m][r] - c, c);
                 }
             }
@@ -632,8 +643,9 @@ static int pack_res_block(const cf_conv_bn* c4, bool first, float eps, std::vect
 }
 
 static void pack_gru_dir(const cf_gru_dir& g, int cin, const float* dense_w /*64 floats of this direction or null*/, float* out) {
-    auto wfull = [&](int in, int o) -> float {
-        return o < 2 * CF_H ? g.gates_kernel[(size_t)in * 2 * CF_H + o] : g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)];
+    auto wfull = [&](int in, int o) -> float {   // pre-scaled: the accumulators are exp2 arguments
+        return o < 2 * CF_H ? (float)(CF_GATE_SCALE * (double)g.gates_kernel[(size_t)in * 2 * CF_H + o])
+                            : (float)(CF_CAND_SCALE * (double)g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)]);
     };
     float* px = out;
     for (int ks = 0; ks < cin / 4; ++ks)
@@ -653,8 +665,8 @@ static void pack_gru_dir(const cf_gru_dir& g, int cin, const float* dense_w /*64
             for (int j = 0; j < 4; ++j)
                 pc[(ks * 64 + lane) * 4 + j] = wfull(cin + frag_feature(ks, lane >> 4), 2 * CF_H + 16 * j + (lane & 15));
     float* pb = out + gru_bias_off(cin);
-    for (int i = 0; i < 2 * CF_H; ++i) pb[i] = g.gates_bias[i];
-    for (int i = 0; i < CF_H; ++i) pb[2 * CF_H + i] = g.candidate_bias[i];
+    for (int i = 0; i < 2 * CF_H; ++i) pb[i] = (float)(CF_GATE_SCALE * (double)g.gates_bias[i]);
+    for (int i = 0; i < CF_H; ++i) pb[2 * CF_H + i] = (float)(CF_CAND_SCALE * (double)g.candidate_bias[i]);
     float* pd = out + gru_dense_off(cin);
     for (int i = 0; i < CF_H; ++i) pd[i] = dense_w ? dense_w[i] : 0.f;
 }

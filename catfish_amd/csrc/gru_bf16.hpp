@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int m = kb >> 1, i = 8 * (kb & 1) + j;
-                    v[j] = cf_sigmoid(acc[m][i]) * h[m][i];
+                    v[j] = cf_sigmoid_pre(acc[m][i]) * h[m][i];
                 }
                 split8<NP>(v, rp[kb]);
             }
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float u = cf_sigmoid(acc[2 + m][i]);
-                    const float c = cf_tanh(acc[4 + m][i]);
+                    const float u = cf_sigmoid_pre(acc[2 + m][i]);
+                    const float c = cf_tanh_pre(acc[4 + m][i]);
                     h[m][i] = fmaf(u, h[m][i] - c, c);
                 }
             }
@@ -233,8 +233,9 @@ static inline float bf16_to_f32(uint16_t b) {
 }
 
 static void pack_gru_dir_bf16(const cf_gru_dir& g, int cin, int np, const float* dense_w, char* out) {
-    auto wfull = [&](int in, int o) -> float {
-        return o < 2 * CF_H ? g.gates_kernel[(size_t)in * 2 * CF_H + o] : g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)];
+    auto wfull = [&](int in, int o) -> float {   // pre-scaled (CF_GATE_SCALE / CF_CAND_SCALE), then split into bf16 parts
+        return o < 2 * CF_H ? (float)(CF_GATE_SCALE * (double)g.gates_kernel[(size_t)in * 2 * CF_H + o])
+                            : (float)(CF_CAND_SCALE * (double)g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)]);
     };
     uint16_t* frag = reinterpret_cast<uint16_t*>(out);
     int p = 0;
@@ -256,7 +257,8 @@ static void pack_gru_dir_bf16(const cf_gru_dir& g, int cin, int np, const float*
         for (int hh = 0; hh < 2; ++hh)
             for (int i = 0; i < 16; ++i) {
                 const int o = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                pb[(mt * 2 + hh) * 16 + i] = o < 2 * CF_H ? g.gates_bias[o] : g.candidate_bias[o - 2 * CF_H];
+                pb[(mt * 2 + hh) * 16 + i] = o < 2 * CF_H ? (float)(CF_GATE_SCALE * (double)g.gates_bias[o])
+                                                          : (float)(CF_CAND_SCALE * (double)g.candidate_bias[o - 2 * CF_H]);
             }
     float* pd = reinterpret_cast<float*>(out + gb_dense_off(cin, np));
     for (int m = 0; m < 2; ++m)
