@@ -389,6 +389,24 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Kernel 1b: plain RNN type (no residual blocks, rnn_class.py:165-175 applied to the raw signal).
+// The GRU kernels want >= 4 input features per k-step, so the single input feature is embedded
+// in a 16-feature fragment tile (feature 0 = x, the rest 0; the packed weight rows are 0 too).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x_nat, f32x4* __restrict__ y_frag,
+                                                    int64_t n_windows, int n_tiles) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (tile, t, lane)
+    if (idx >= (int64_t)n_tiles * CF_T * 64) return;
+    const int lane = (int)(idx & 63);
+    const int64_t tt = idx >> 6;
+    const int t = (int)(tt % CF_T);
+    const int64_t w = (tt / CF_T) * CF_TILE + (lane & 15);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((lane >> 4) == 0 && w < n_windows) v.x = x_nat[w * CF_T + t];
+    y_frag[idx] = v;
+}
+
 #include "gru_bf16.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -642,8 +660,11 @@ static int pack_res_block(const cf_conv_bn* c4, bool first, float eps, std::vect
     return CF_OK;
 }
 
-static void pack_gru_dir(const cf_gru_dir& g, int cin, const float* dense_w /*64 floats of this direction or null*/, float* out) {
+static void pack_gru_dir(const cf_gru_dir& g, int cin, int cin_real, const float* dense_w /*64 floats of this direction or null*/,
+                         float* out) {
+    // cin = padded input width of the kernel instantiation, cin_real = rows of the x part in the checkpoint
     auto wfull = [&](int in, int o) -> float {   // pre-scaled: the accumulators are exp2 arguments
+        if (in < 0) return 0.f;
         return o < 2 * CF_H ? (float)(CF_GATE_SCALE * (double)g.gates_kernel[(size_t)in * 2 * CF_H + o])
                             : (float)(CF_CAND_SCALE * (double)g.candidate_kernel[(size_t)in * CF_H + (o - 2 * CF_H)]);
     };
@@ -652,18 +673,19 @@ static void pack_gru_dir(const cf_gru_dir& g, int cin, const float* dense_w /*64
         for (int gq = 0; gq < 3; ++gq)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j)
-                    px[((ks * 3 + gq) * 64 + lane) * 4 + j] = wfull(frag_feature(ks, lane >> 4), 16 * (4 * gq + j) + (lane & 15));
+                    px[((ks * 3 + gq) * 64 + lane) * 4 + j] =
+                        wfull(frag_feature(ks, lane >> 4) < cin_real ? frag_feature(ks, lane >> 4) : -1, 16 * (4 * gq + j) + (lane & 15));
     float* pg = out + gru_x_floats(cin);
     for (int ks = 0; ks < 16; ++ks)
         for (int gq = 0; gq < 2; ++gq)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j)
-                    pg[((ks * 2 + gq) * 64 + lane) * 4 + j] = wfull(cin + frag_feature(ks, lane >> 4), 16 * (4 * gq + j) + (lane & 15));
+                    pg[((ks * 2 + gq) * 64 + lane) * 4 + j] = wfull(cin_real + frag_feature(ks, lane >> 4), 16 * (4 * gq + j) + (lane & 15));
     float* pc = pg + gru_hg_floats();
     for (int ks = 0; ks < 16; ++ks)
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 4; ++j)
-                pc[(ks * 64 + lane) * 4 + j] = wfull(cin + frag_feature(ks, lane >> 4), 2 * CF_H + 16 * j + (lane & 15));
+                pc[(ks * 64 + lane) * 4 + j] = wfull(cin_real + frag_feature(ks, lane >> 4), 2 * CF_H + 16 * j + (lane & 15));
     float* pb = out + gru_bias_off(cin);
     for (int i = 0; i < 2 * CF_H; ++i) pb[i] = (float)(CF_GATE_SCALE * (double)g.gates_bias[i]);
     for (int i = 0; i < CF_H; ++i) pb[2 * CF_H + i] = (float)(CF_CAND_SCALE * (double)g.candidate_bias[i]);
@@ -702,9 +724,12 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
     if (hp->window != CF_T) return fail(CF_ERR_INVALID, "window must be 35 (rnn_class.py:27)");
     if (hp->layer_size != CF_H || hp->n_layers < 1)
         return fail(CF_ERR_INVALID, "kernels are specialised for layer_size = 64, n_layers >= 1");
-    if (hp->n_layers_res < 1 || hp->layer_size_res != CF_C)
-        return fail(CF_ERR_INVALID, "kernels are specialised for layer_size_res = 32, n_layers_res >= 1 (ResNetRNN)");
-    if (!w->conv || !w->gru || !w->dense_kernel || !w->dense_bias) return fail(CF_ERR_INVALID, "cf_weights has null members");
+    if (hp->n_layers_res < 0 || (hp->n_layers_res > 0 && hp->layer_size_res != CF_C))
+        return fail(CF_ERR_INVALID, "kernels are specialised for layer_size_res = 32 (ResNetRNN) or n_layers_res = 0 (RNN)");
+    if (hp->n_layers_res == 0 && hp->precision != CF_PREC_FP32)
+        return fail(CF_ERR_INVALID, "the plain RNN type (n_layers_res = 0) is only built for CF_PREC_FP32");
+    if ((hp->n_layers_res > 0 && !w->conv) || !w->gru || !w->dense_kernel || !w->dense_bias)
+        return fail(CF_ERR_INVALID, "cf_weights has null members");
     int n_dev = 0;
     HIP_TRY(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev) return fail(CF_ERR_INVALID, "device index out of range");
@@ -727,12 +752,14 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
     }
     // GRU layers
     for (int l = 0; l < hp->n_layers && rc == CF_OK; ++l) {
-        const int cin = l == 0 ? CF_C : 2 * CF_H;
-        if (w->gru[2 * l].cin != cin || w->gru[2 * l + 1].cin != cin) { rc = fail(CF_ERR_INVALID, "GRU layer input width mismatch"); break; }
+        const int cin_real = l == 0 ? (hp->n_layers_res > 0 ? CF_C : 1) : 2 * CF_H;
+        const int cin = cin_real == 1 ? 16 : cin_real;     // RNN type: the raw sample embedded in 16 features
+        if (w->gru[2 * l].cin != cin_real || w->gru[2 * l + 1].cin != cin_real) { rc = fail(CF_ERR_INVALID, "GRU layer input width mismatch"); break; }
         const bool last = l == hp->n_layers - 1;
         std::vector<float> blob((size_t)2 * gru_pack_floats(cin));
         for (int d = 0; d < 2; ++d)
-            pack_gru_dir(w->gru[2 * l + d], cin, last ? w->dense_kernel + d * CF_H : nullptr, blob.data() + (size_t)d * gru_pack_floats(cin));
+            pack_gru_dir(w->gru[2 * l + d], cin, cin_real, last ? w->dense_kernel + d * CF_H : nullptr,
+                         blob.data() + (size_t)d * gru_pack_floats(cin));
         float* dptr = nullptr;
         rc = upload(blob, &dptr);
         m->d_gru.push_back(dptr);
@@ -778,6 +805,8 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         // opt in to > 64 KiB dynamic LDS for every GRU instantiation we may launch
         hipError_t e = hipSuccess;
         auto optin = [&](const void* f, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+        optin((const void*)gru_layer_kernel<16, false>, gru_pack_floats(16) * 4);
+        optin((const void*)gru_layer_kernel<16, true>, gru_pack_floats(16) * 4);
         optin((const void*)gru_layer_kernel<32, false>, gru_pack_floats(32) * 4);
         optin((const void*)gru_layer_kernel<32, true>, gru_pack_floats(32) * 4);
         optin((const void*)gru_layer_kernel<128, false>, gru_pack_floats(128) * 4);
@@ -886,7 +915,15 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     }
-    const float* cur = sl.d_a[(m->hp.n_layers_res - 1) & 1];
+    if (m->hp.n_layers_res == 0) {
+        if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
+        const int64_t n_el = (int64_t)n_tiles * CF_T * 64;
+        hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, x,
+                           reinterpret_cast<f32x4*>(sl.d_a[0]), n_windows, n_tiles);
+        HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+    }
+    const float* cur = m->hp.n_layers_res == 0 ? sl.d_a[0] : sl.d_a[(m->hp.n_layers_res - 1) & 1];
     // GRU layers
     for (int l = 0; l < m->hp.n_layers; ++l) {
         const bool last = l == m->hp.n_layers - 1;
@@ -894,6 +931,9 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         if (m->np > 0) {
             rc = m->np == 1 ? launch_gru_bf16_layer<1>(m, l, last, cur, y, sl.d_p, n_tiles32, s)
                             : launch_gru_bf16_layer<2>(m, l, last, cur, y, sl.d_p, n_tiles32, s);
+        } else if (l == 0 && m->hp.n_layers_res == 0) {
+            rc = last ? launch_gru<16, true>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU_LAST)
+                      : launch_gru<16, false>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU0);
         } else if (l == 0) {
             rc = last ? launch_gru<32, true>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU_LAST)
                       : launch_gru<32, false>(m, m->d_gru[l], cur, y, sl.d_p, n_tiles, s, SLOT_GRU0);

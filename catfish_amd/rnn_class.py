@@ -200,5 +200,19 @@ class RNN(object):
         self.train_loss = self._trainer.train_step(train_x, train_y)
         self._engine_stale = True
 
+    def save_network(self, path, step):
+        """Write the current weights as a TensorFlow checkpoint-V2 bundle ``path/ckpnt-<step>`` that the
+        original tool's ``restore_network`` (rnn_class.py:191-198) and this one can both read
+        (the reference saves with ``saver.save(sess, ".../checkpoints/ckpnt", global_step=step)``,
+        networks/train_validate.py:154-155).  Optimizer slots are not written."""
+        if self.weights is None:
+            raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
+        weights = self._trainer.net.numpy_weights() if self._trainer is not None else self.weights
+        prefix = os.path.join(path, "ckpnt-%d" % int(step))
+        checkpoint.write_checkpoint(prefix, {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()})
+        with open(os.path.join(path, "checkpoint"), "w") as fh:
+            fh.write('model_checkpoint_path: "ckpnt-%d"\nall_model_checkpoint_paths: "ckpnt-%d"\n' % (int(step), int(step)))
+        return prefix
+
     def save_info(self):
         raise NotImplementedError("save_info (rnn_class.py:264-270) belongs to the training stack")

@@ -197,3 +197,35 @@ def test_train_network_then_infer_uses_updated_weights(hp):
     want = oracle.forward(x[:32], m._trainer.net.numpy_weights(), np.float64)
     assert np.abs(after - want).max() < 1e-4
     m.engine.close()
+
+
+def test_plain_rnn_type_matches_oracle(hp):
+    """build_model("RNN") (neural_network.py:17-18): 3 x biGRU directly on the raw window, no residual blocks."""
+    from catfish_amd import neural_network
+    m = neural_network.build_model("RNN", **hp)
+    assert m.model_type == "biGRU-RNN"
+    w = oracle.random_weights(seed=21, n_layers_res=0)
+    m.set_weights(w)
+    rng = np.random.default_rng(1)
+    x = rng.normal(0, 1.3, size=(77, 35, 1))
+    got = m.infer(x)
+    want = oracle.forward(x, w, np.float64, n_layers_res=0)
+    assert np.abs(got - want).max() < 1e-4
+    stage = m.engine.debug_stage(0, 16)
+    _, st = oracle.forward(x[:16], w, np.float64, n_layers_res=0, return_stages=True)
+    assert np.abs(stage - st["gru0"]).max() < 2e-5
+    m.engine.close()
+    with pytest.raises(ValueError):
+        from catfish_amd.engine import HipEngine
+        HipEngine(w, n_layers_res=0, precision="bf16")
+
+
+def test_save_network_round_trip(model, tmp_path, hp):
+    from catfish_amd.resnet_class import ResNetRNN
+    prefix = model.save_network(str(tmp_path), 123)
+    assert prefix.endswith("ckpnt-123")
+    m2 = ResNetRNN(**hp)
+    m2.restore_network(str(tmp_path), ckpnt="latest")
+    x = np.random.default_rng(0).normal(size=(20, 35, 1))
+    assert np.array_equal(m2.infer(x), model.infer(x))
+    m2.engine.close()
