@@ -119,11 +119,7 @@ __device__ __forceinline__ void unit_mma(const float* __restrict__ unit, int lan
     }
 }
 
-// OUTP = 0: fp32 fragment layout (tile16) for the next fp32 kernel.
-// OUTP = 1/2: bf16 parts in the 32-window B-operand layout of gru_layer_bf16_kernel
-//             ([tile32][t][kb < 2][part < OUTP][lane][8 bf16]); a lane (window w, quarter q, M-tile m) owns
-//             elements j = 4(q>>1)..+3 of lane-half q&1, k-block m.
-template <bool FIRST, int OUTP>
+template <bool FIRST>
 __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict__ wpack,
                                                         const float* __restrict__ x_nat,   // FIRST: [n_windows, 35]
                                                         const f32x4* __restrict__ x_frag,  // !FIRST: [tile][t][2][lane]
@@ -199,27 +195,9 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
                 f32x4 o2[2] = {relu4(acc[0]), relu4(acc[1])};                 // (:69-71)
                 f32x4 acc3[2] = {vec(VB3 + 1, 0), vec(VB3 + 1, 1)};
                 unit_mma(lds + (U3 + 3) * 1024, lane, o2, acc3);              // last conv (:74-76)
-                const f32x4 o0 = relu4(relu4(acc3[0]) + sc_p[0]);             // add + relu (:79-80)
-                const f32x4 o1 = relu4(relu4(acc3[1]) + sc_p[1]);
-                if constexpr (OUTP == 0) {
-                    f32x4* dst = y_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
-                    dst[0] = o0;
-                    dst[64] = o1;
-                } else {
-                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                    char* base = reinterpret_cast<char*>(y_frag) +
-                                 (((int64_t)(tile >> 1) * CF_T + (i - 1)) * 2 * OUTP) * 1024 +
-                                 ((q & 1) * 32 + (tile & 1) * 16 + (lane & 15)) * 16 + (q >> 1) * 8;
-#pragma unroll
-                    for (int mo = 0; mo < 2; ++mo) {
-                        const f32x4 o = mo == 0 ? o0 : o1;
-                        bf16x4_t hi, lo;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { hi[r] = (__bf16)o[r]; lo[r] = (__bf16)(o[r] - (float)hi[r]); }
-                        *reinterpret_cast<bf16x4_t*>(base + (mo * OUTP + 0) * 1024) = hi;
-                        if constexpr (OUTP == 2) *reinterpret_cast<bf16x4_t*>(base + (mo * OUTP + 1) * 1024) = lo;
-                    }
-                }
+                f32x4* dst = y_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
+                dst[0] = relu4(relu4(acc3[0]) + sc_p[0]);                     // add + relu (:79-80)
+                dst[64] = relu4(relu4(acc3[1]) + sc_p[1]);
             }
 #pragma unroll
             for (int mo = 0; mo < 2; ++mo) { o1_pp[mo] = o1_p[mo]; o1_p[mo] = o1_c[mo]; sc_p[mo] = sc_c[mo]; }
@@ -567,6 +545,7 @@ struct cf_model {
     std::vector<float*> d_res;   // per residual block packed weights
     std::vector<float*> d_gru;   // per layer packed weights [2 dirs]
     std::vector<int> gru_cin;
+    std::vector<char*> d_res_b;  // per residual block packed bf16 weights (precision != fp32)
     std::vector<char*> d_gru_b;  // per layer packed bf16 weights [2 dirs] (precision != fp32)
     int np = 0;                  // bf16 parts per operand: 0 = fp32 path, 1 = bf16, 2 = bf16x3
     float dense_bias = 0.f;
@@ -660,6 +639,31 @@ static int pack_res_block(const cf_conv_bn* c4, bool first, float eps, std::vect
     return CF_OK;
 }
 
+static int pack_res_block_bf16(const cf_conv_bn* c4, bool first, float eps, int np, std::vector<char>& out) {
+    out.assign(rb_pack_bytes(first, np), 0);
+    const FoldedConv sc = fold(c4[0], eps), f1 = fold(c4[1], eps), f3 = fold(c4[2], eps), fl = fold(c4[3], eps);
+    const int cin = first ? 1 : CF_C;
+    if (sc.k != 1 || f1.k != 1 || f3.k != 3 || fl.k != 1 || sc.cin != cin || f1.cin != cin || f3.cin != CF_C || fl.cin != CF_C)
+        return fail(CF_ERR_INVALID, "residual block geometry not supported (need k = 1,1,3,1 and 32 channels)");
+    const size_t ub = (size_t)2 * np * 1024;     // bytes per unit
+    char* vecs = out.data() + rb_vec_off(first, np);
+    if (first) {
+        for (int k = 0; k < 3; ++k) pack_unit_bf16(out.data() + k * ub, tap(f3, k), np);
+        pack_unit_bf16(out.data() + 3 * ub, tap(fl, 0), np);
+        pack_vec32(vecs + 0 * 128, f3.b); pack_vec32(vecs + 1 * 128, fl.b);
+        pack_vec32(vecs + 2 * 128, sc.w); pack_vec32(vecs + 3 * 128, sc.b);
+        pack_vec32(vecs + 4 * 128, f1.w); pack_vec32(vecs + 5 * 128, f1.b);
+    } else {
+        pack_unit_bf16(out.data() + 0 * ub, tap(sc, 0), np);
+        pack_unit_bf16(out.data() + 1 * ub, tap(f1, 0), np);
+        for (int k = 0; k < 3; ++k) pack_unit_bf16(out.data() + (2 + k) * ub, tap(f3, k), np);
+        pack_unit_bf16(out.data() + 5 * ub, tap(fl, 0), np);
+        pack_vec32(vecs + 0 * 128, sc.b); pack_vec32(vecs + 1 * 128, f1.b);
+        pack_vec32(vecs + 2 * 128, f3.b); pack_vec32(vecs + 3 * 128, fl.b);
+    }
+    return CF_OK;
+}
+
 static void pack_gru_dir(const cf_gru_dir& g, int cin, int cin_real, const float* dense_w /*64 floats of this direction or null*/,
                          float* out) {
     // cin = padded input width of the kernel instantiation, cin_real = rows of the x part in the checkpoint
@@ -706,6 +710,7 @@ extern "C" void cf_model_destroy(cf_model* m) {
     for (float* p : m->d_res) if (p) (void)hipFree(p);
     for (float* p : m->d_gru) if (p) (void)hipFree(p);
     for (char* p : m->d_gru_b) if (p) (void)hipFree(p);
+    for (char* p : m->d_res_b) if (p) (void)hipFree(p);
     for (auto& sl : m->slots) {
         for (int i = 0; i < 2; ++i) { if (sl.d_a[i]) (void)hipFree(sl.d_a[i]); if (sl.d_y[i]) (void)hipFree(sl.d_y[i]); }
         if (sl.d_p) (void)hipFree(sl.d_p);
@@ -749,6 +754,17 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         std::vector<float> blob;
         rc = pack_res_block(w->conv + 4 * b, b == 0, hp->bn_epsilon, blob);
         if (rc == CF_OK) { float* d = nullptr; rc = upload(blob, &d); m->d_res.push_back(d); }
+        if (rc == CF_OK && m->np > 0) {
+            std::vector<char> bblob;
+            rc = pack_res_block_bf16(w->conv + 4 * b, b == 0, hp->bn_epsilon, m->np, bblob);
+            if (rc == CF_OK) {
+                char* bptr = nullptr;
+                hipError_t e = hipMalloc((void**)&bptr, bblob.size());
+                if (e == hipSuccess) e = hipMemcpy(bptr, bblob.data(), bblob.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(CF_ERR_HIP, std::string("bf16 conv weight upload: ") + hipGetErrorString(e));
+                m->d_res_b.push_back(bptr);
+            }
+        }
     }
     // GRU layers
     for (int l = 0; l < hp->n_layers && rc == CF_OK; ++l) {
@@ -897,19 +913,37 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     const int res_grid = std::min((n_tiles + 3) / 4, m->n_cu * 4);
     for (int b = 0; b < m->hp.n_layers_res; ++b) {
         float* dst = sl.d_a[b & 1];
-        if (b == 0) {
+        if (m->np > 0) {
+            // residual blocks on the bf16 matrix pipe, 32-window tiles
+            const int grid32 = std::min((n_tiles32 + 3) / 4, m->n_cu * 4);
+            if ((rc = prof_begin(m, b == 0 ? SLOT_RES_FIRST : SLOT_RES, s, &pi)) != CF_OK) return rc;
+            const bf16x8* src = b == 0 ? nullptr : reinterpret_cast<const bf16x8*>(sl.d_a[(b - 1) & 1]);
+            if (b == 0) {
+                const int lds_bytes = rb_pack_bytes(true, m->np > 1 ? 2 : 1) + 4 * 32 * CF_T * 4;
+                if (m->np == 1)
+                    hipLaunchKernelGGL((res_block_bf16_kernel<true, 1>), dim3(grid32), dim3(256), lds_bytes, s, m->d_res_b[0], x, src,
+                                       reinterpret_cast<bf16x8*>(dst), n_windows, n_tiles32);
+                else
+                    hipLaunchKernelGGL((res_block_bf16_kernel<true, 2>), dim3(grid32), dim3(256), lds_bytes, s, m->d_res_b[0], x, src,
+                                       reinterpret_cast<bf16x8*>(dst), n_windows, n_tiles32);
+            } else {
+                const int lds_bytes = rb_pack_bytes(false, m->np > 1 ? 2 : 1);
+                if (m->np == 1)
+                    hipLaunchKernelGGL((res_block_bf16_kernel<false, 1>), dim3(grid32), dim3(256), lds_bytes, s, m->d_res_b[b],
+                                       (const float*)nullptr, src, reinterpret_cast<bf16x8*>(dst), n_windows, n_tiles32);
+                else
+                    hipLaunchKernelGGL((res_block_bf16_kernel<false, 2>), dim3(grid32), dim3(256), lds_bytes, s, m->d_res_b[b],
+                                       (const float*)nullptr, src, reinterpret_cast<bf16x8*>(dst), n_windows, n_tiles32);
+            }
+        } else if (b == 0) {
             if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = (res_pack_floats(true) + 4 * CF_TILE * CF_T) * 4;
-            const bool lastb = m->hp.n_layers_res == 1;
-            auto kfn = (lastb && m->np == 1) ? res_block_kernel<true, 1> : (lastb && m->np == 2) ? res_block_kernel<true, 2> : res_block_kernel<true, 0>;
-            hipLaunchKernelGGL(kfn, dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[0], x,
+            hipLaunchKernelGGL((res_block_kernel<true>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[0], x,
                                (const f32x4*)nullptr, reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         } else {
             if ((rc = prof_begin(m, SLOT_RES, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = res_pack_floats(false) * 4;
-            const bool lastb = b == m->hp.n_layers_res - 1;
-            auto kfn = (lastb && m->np == 1) ? res_block_kernel<false, 1> : (lastb && m->np == 2) ? res_block_kernel<false, 2> : res_block_kernel<false, 0>;
-            hipLaunchKernelGGL(kfn, dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
+            hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
                                reinterpret_cast<const f32x4*>(sl.d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         }
         HIP_TRY(hipGetLastError());

@@ -217,6 +217,152 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Residual block on the bf16 matrix pipe (used when precision != fp32): same streaming structure as
+// res_block_kernel, tile = 32 windows, every 32x32 conv unit = 2 k-blocks x (1 or 3) MFMAs.
+// Blob (bytes): units [unit][kb < 2][part < NP] fragments of 1 KiB, then fp32 vectors [vec][hh < 2][16]:
+//   first block: units {c3 tap0, tap1, tap2, last}, vectors {b_c3, b_last, w_sc, b_sc, w_first, b_first}
+//   other blocks: units {sc, first, c3 tap0, tap1, tap2, last}, vectors {b_sc, b_first, b_c3, b_last}
+// Activations in and out: [tile32][t][kb < 2][part][lane][8 bf16] (the GRU kernels' input layout).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int rb_vec_off(bool first, int np) { return res_units(first) * 2 * np * 1024; }
+__host__ __device__ constexpr int rb_pack_bytes(bool first, int np) { return rb_vec_off(first, np) + res_vecs(first) * 128; }
+
+template <int NP>
+__device__ __forceinline__ void split16(const f32x16& v, bf16x8 (&out)[2][NP]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[8 * kb + j];
+        split8<NP>(t, out[kb]);
+    }
+}
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    return v;
+}
+
+template <bool FIRST, int NP>
+__global__ __launch_bounds__(256) void res_block_bf16_kernel(const char* __restrict__ wpack,
+                                                             const float* __restrict__ x_nat,    // FIRST: [n_windows, 35]
+                                                             const bf16x8* __restrict__ x_in,    // !FIRST
+                                                             bf16x8* __restrict__ y_out,
+                                                             int64_t n_windows, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK = rb_pack_bytes(FIRST, NP);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < PACK / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hh = lane >> 5;
+    const int nwaves = blockDim.x >> 6;
+    const bf16x8* WU = reinterpret_cast<const bf16x8*>(lds) + lane;                          // + ((unit*2 + kb)*NP + part)*64
+    const char* vbase = reinterpret_cast<const char*>(lds) + rb_vec_off(FIRST, NP) + hh * 64;
+    float* xs = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PACK) + wave * (32 * CF_T);   // FIRST: x tile [32][35]
+
+    auto vec = [&](int v) -> f32x16 {
+        f32x16 o;
+        const f32x4* p = reinterpret_cast<const f32x4*>(vbase + v * 128);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 b = p[c4];
+            o[4 * c4 + 0] = b.x; o[4 * c4 + 1] = b.y; o[4 * c4 + 2] = b.z; o[4 * c4 + 3] = b.w;
+        }
+        return o;
+    };
+    auto unit = [&](int u, const bf16x8 (&in)[2][NP], f32x16 acc) -> f32x16 {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 a[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = WU[((u * 2 + kb) * NP + p) * 64];
+            acc = prod<NP>(a, in[kb], acc);
+        }
+        return acc;
+    };
+
+    for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves) {
+        if constexpr (FIRST) {
+            const int64_t base = (int64_t)tile * 32 * CF_T;
+            const int64_t limit = n_windows * CF_T;
+            for (int i = lane; i < 32 * CF_T; i += 64) xs[i] = (base + i < limit) ? x_nat[base + i] : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        bf16x8 o1pp[2][NP], o1p[2][NP], o1c[2][NP];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o1pp[kb][p][j] = (__bf16)0.f; o1p[kb][p][j] = (__bf16)0.f; }
+        f32x16 sc_p, sc_c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sc_p[i] = 0.f; sc_c[i] = 0.f; }
+        for (int i = 0; i <= CF_T; ++i) {
+            if (i < CF_T) {
+                if constexpr (FIRST) {
+                    const float xv = xs[(lane & 31) * CF_T + i];
+                    const f32x16 w_sc = vec(2), b_sc = vec(3), w_f = vec(4), b_f = vec(5);
+                    f32x16 o1;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { sc_c[k] = fmaf(w_sc[k], xv, b_sc[k]); o1[k] = fmaxf(fmaf(w_f[k], xv, b_f[k]), 0.f); }
+                    split16<NP>(o1, o1c);
+                } else {
+                    bf16x8 in[2][NP];
+                    const bf16x8* src = x_in + (((int64_t)tile * CF_T + i) * 2) * NP * 64 + lane;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) in[kb][p] = src[(kb * NP + p) * 64];
+                    sc_c = unit(0, in, vec(0));                               // shortcut, no relu
+                    split16<NP>(relu16(unit(1, in, vec(1))), o1c);            // first conv + relu
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o1c[kb][p][j] = (__bf16)0.f;   // zero padding past the window end
+            }
+            if (i >= 1) {
+                constexpr int U3 = FIRST ? 0 : 2;
+                constexpr int VB3 = FIRST ? 0 : 2;
+                f32x16 acc = vec(VB3);
+                acc = unit(U3 + 0, o1pp, acc);
+                acc = unit(U3 + 1, o1p, acc);
+                acc = unit(U3 + 2, o1c, acc);
+                bf16x8 o2[2][NP];
+                split16<NP>(relu16(acc), o2);
+                f32x16 out = relu16(unit(U3 + 3, o2, vec(VB3 + 1)));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) out[k] = fmaxf(out[k] + sc_p[k], 0.f);
+                bf16x8 op[2][NP];
+                split16<NP>(out, op);
+                bf16x8* dst = y_out + (((int64_t)tile * CF_T + (i - 1)) * 2) * NP * 64 + lane;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) dst[(kb * NP + p) * 64] = op[kb][p];
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { o1pp[kb][p] = o1p[kb][p]; o1p[kb][p] = o1c[kb][p]; }
+            sc_p = sc_c;
+        }
+        if constexpr (FIRST) __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- host-side packing -------------------------------------------------------------------
 static inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;
@@ -265,4 +411,23 @@ static void pack_gru_dir_bf16(const cf_gru_dir& g, int cin, int np, const float*
         for (int hh = 0; hh < 2; ++hh)
             for (int i = 0; i < 16; ++i)
                 pd[(m * 2 + hh) * 16 + i] = dense_w ? dense_w[32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh] : 0.f;
+}
+
+// 32x32 conv unit -> [kb < 2][part][lane][8 bf16]: A[row = out feature lane&31][k] with k = frag_feature32(kb, hh, j)
+static void pack_unit_bf16(char* dst, const std::vector<double>& w /*[32 in][32 out]*/, int np) {
+    uint16_t* frag = reinterpret_cast<uint16_t*>(dst);
+    for (int kb = 0; kb < 2; ++kb)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)w[frag_feature32(kb, lane >> 5, j) * 32 + (lane & 31)];
+                const uint16_t hi = f32_to_bf16_rne(v);
+                frag[((size_t)(kb * np + 0) * 64 + lane) * 8 + j] = hi;
+                if (np == 2) frag[((size_t)(kb * np + 1) * 64 + lane) * 8 + j] = f32_to_bf16_rne(v - bf16_to_f32(hi));
+            }
+}
+// fp32 vector in D-layout order: [hh][i] = v[(i&3) + 8(i>>2) + 4hh]
+static void pack_vec32(char* dst, const std::vector<double>& v) {
+    float* o = reinterpret_cast<float*>(dst);
+    for (int hh = 0; hh < 2; ++hh)
+        for (int i = 0; i < 16; ++i) o[hh * 16 + i] = (float)v[(i & 3) + 8 * (i >> 2) + 4 * hh];
 }
