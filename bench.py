@@ -197,7 +197,7 @@ def main():
             if prec == args.precision:
                 continue
             e2 = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, precision=prec)
-            for i in range(2):
+            for i in range(6):
                 e2.infer_device(batches[i % n_batches], out=outs[i & 1])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
