@@ -69,6 +69,7 @@ SYMBOLS = {
     "cf_infer_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cf_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "cf_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cf_profile_reset": (C.c_int, [C.c_void_p]),

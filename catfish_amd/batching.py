@@ -96,6 +96,16 @@ def spans_from_labels(labels, sample_offsets, n_reads, ext_left=EXT_LEFT, ext_ri
     return out
 
 
+def spans_from_runs(starts, ends, sample_offsets, n_reads, ext_left=EXT_LEFT, ext_right=EXT_RIGHT):
+    """Sorted packed run boundaries (engine.spans_device) -> per-read [start - 11, end + 16] lists."""
+    read_of = np.searchsorted(sample_offsets, starts, side="right") - 1
+    base = sample_offsets[read_of]
+    out = [[] for _ in range(n_reads)]
+    for r, s, e in zip(read_of.tolist(), (starts - base).tolist(), (ends - base).tolist()):
+        out[r].append([s - ext_left, e + ext_right])
+    return out
+
+
 def infer_packed(engine, packed, threshold=0.5, min_run=15, return_probs=False):
     """PackedReads -> list of (spans, read length) per read, optionally with per-read probabilities."""
     import torch
@@ -105,8 +115,8 @@ def infer_packed(engine, packed, threshold=0.5, min_run=15, return_probs=False):
     lens = torch.from_numpy(packed.lengths).to(dev)
     probs = engine.infer_device(x)
     labels = engine.postprocess_device(probs, offs, lens, threshold=threshold, min_run=min_run)
-    lab_h = labels.cpu().numpy()
-    spans = spans_from_labels(lab_h, packed.sample_offsets, packed.n_reads)
+    starts, ends = engine.spans_device(labels)
+    spans = spans_from_runs(starts, ends, packed.sample_offsets, packed.n_reads)
     result = [(spans[i], int(packed.lengths[i])) for i in range(packed.n_reads)]
     if return_probs:
         p = probs.cpu().numpy()
@@ -165,7 +175,8 @@ def infer_reads_dac(model, dac_reads, max_windows=None, threshold=0.5, min_run=1
         s_off = win_off * WINDOW_SIZE
         labels = engine.postprocess_device(probs, torch.from_numpy(s_off).to(dev), torch.from_numpy(lengths).to(dev),
                                            threshold=threshold, min_run=min_run)
-        spans = spans_from_labels(labels.cpu().numpy(), s_off, len(bucket))
+        starts, ends = engine.spans_device(labels)
+        spans = spans_from_runs(starts, ends, s_off, len(bucket))
         p_host = probs.cpu().numpy() if return_probs else None
         for k, i in enumerate(bucket):
             out[i] = (spans[k], int(lengths[k]))

@@ -438,6 +438,27 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel 4b: run boundaries of the corrected labels (first half of hp_in_pred, infer.py:141-162).
+// Every sample that opens (closes) a positive run appends its packed position to `starts`
+// (`ends`, exclusive) through an atomic counter.  Padding labels are 0, so runs never cross reads;
+// after sorting both lists ascending on the host the k-th start pairs with the k-th end.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spans_kernel(const uint8_t* __restrict__ labels, int64_t total, int64_t max_runs,
+                                                    int64_t* __restrict__ starts, int64_t* __restrict__ ends,
+                                                    unsigned long long* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total || !labels[i]) return;
+    if (i == 0 || !labels[i - 1]) {
+        const unsigned long long k = atomicAdd(&counts[0], 1ull);
+        if ((int64_t)k < max_runs) starts[k] = i;
+    }
+    if (i == total - 1 || !labels[i + 1]) {
+        const unsigned long long k = atomicAdd(&counts[1], 1ull);
+        if ((int64_t)k < max_runs) ends[k] = i + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 5: signal ingest -- per-read median / MAD normalisation of raw int16 DAC samples
 // (normalize_raw_signal, infer.py:96-105) fused with the zero padding + window packing of
 // infer.py:31-43.  One workgroup per read.  Medians are found exactly by radix selection over
@@ -1072,6 +1093,22 @@ extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* re
                        read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
+}
+
+extern "C" int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_samples, int64_t max_runs, int64_t* starts,
+                        int64_t* ends, uint64_t* counts, void* stream) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_spans: null model");
+    if (total_samples < 0 || max_runs < 0) return fail(CF_ERR_INVALID, "cf_spans: negative size");
+    if (!counts) return fail(CF_ERR_INVALID, "cf_spans: null counts");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(uint64_t), s));
+    if (total_samples == 0) return CF_OK;
+    if (!labels || (max_runs > 0 && (!starts || !ends))) return fail(CF_ERR_INVALID, "cf_spans: null buffer");
+    hipLaunchKernelGGL(spans_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, labels, total_samples, max_runs,
+                       starts, ends, reinterpret_cast<unsigned long long*>(counts));
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
 }
 
 extern "C" int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets, const int64_t* win_offsets,

@@ -118,6 +118,31 @@ class HipEngine(object):
                                          C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream)))
         return out
 
+    def spans_device(self, labels, max_runs=None, stream=None):
+        """Device run-length pass over corrected labels -> (starts, ends) numpy int64, sorted ascending
+        (packed positions; ends exclusive).  Only the two short lists cross PCIe."""
+        import torch
+        if labels.dtype != torch.uint8 or not labels.is_cuda or not labels.is_contiguous():
+            raise ValueError("labels must be a contiguous uint8 CUDA tensor")
+        total = int(labels.numel())
+        if max_runs is None:
+            max_runs = total // 15 + 16          # correct_short leaves runs of >= 15 samples
+        dev = labels.device
+        starts = torch.empty(max_runs, dtype=torch.int64, device=dev)
+        ends = torch.empty(max_runs, dtype=torch.int64, device=dev)
+        counts = torch.empty(2, dtype=torch.int64, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        N.check(self._lib.cf_spans(self._handle, C.c_void_p(labels.data_ptr()), total, int(max_runs),
+                                   C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()),
+                                   C.c_void_p(counts.data_ptr()), C.c_void_p(stream.cuda_stream)))
+        n_s, n_e = (int(v) for v in counts.cpu().tolist())
+        if n_s != n_e:
+            raise RuntimeError("cf_spans: %d run starts but %d run ends" % (n_s, n_e))
+        if n_s > max_runs:
+            return self.spans_device(labels, max_runs=n_s, stream=stream)
+        return np.sort(starts[:n_s].cpu().numpy()), np.sort(ends[:n_e].cpu().numpy())
+
     def normalize_device(self, dac, dac_offsets, win_offsets, out=None, stream=None):
         """Device median/MAD normalisation + padding + window packing of many int16 reads.
 

@@ -122,6 +122,15 @@ int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets,
                    const int64_t* read_lengths, int64_t n_reads, int64_t total_samples,
                    float threshold, int32_t min_run, uint8_t* labels, void* stream);
 
+/* Run boundaries of the corrected labels on device (the run-length half of hp_in_pred,
+ * catfish/infer.py:141-162).  labels: device uint8[total_samples] as written by cf_postprocess
+ * (padding = 0, so runs never cross reads).  starts / ends: device int64[max_runs], receive the packed
+ * positions of every run's first sample and one-past-last sample in arbitrary order (sort both
+ * ascending: the k-th start pairs with the k-th end); counts: device uint64[2] = number of starts and
+ * of ends found (may exceed max_runs, in which case the lists are truncated). */
+int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_samples, int64_t max_runs,
+             int64_t* starts, int64_t* ends, uint64_t* counts, void* stream);
+
 /* Signal ingest on device, replacing normalize_raw_signal + the padding / reshape of
  * infer_class_from_signal (catfish/infer.py:96-105, 31-43) for many reads at once.
  * dac: device int16, the reads' raw DAC samples back to back (after the leader trim of

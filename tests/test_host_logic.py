@@ -120,6 +120,19 @@ def test_spans_from_packed_labels_match_per_read_reference_logic():
         assert got[i] == want
 
 
+def test_spans_from_runs_equals_spans_from_labels():
+    rng = np.random.default_rng(6)
+    lens = [40, 35, 700, 123, 70, 2000]
+    pk = batching.pack_reads([np.zeros(n) for n in lens])
+    labels = np.zeros(pk.n_windows * 35, dtype=np.uint8)
+    for i, n in enumerate(lens):
+        labels[pk.sample_offsets[i]:pk.sample_offsets[i] + n] = oracle.correct_short((rng.random(n) < 0.8).astype(int))
+    d = np.diff(np.concatenate(([0], labels.astype(np.int8), [0])))
+    starts, ends = np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+    assert batching.spans_from_runs(starts, ends, pk.sample_offsets, pk.n_reads) == \
+        batching.spans_from_labels(labels, pk.sample_offsets, pk.n_reads)
+
+
 def test_shard_reads_balanced_and_complete():
     rng = np.random.default_rng(7)
     lens = np.exp(rng.uniform(np.log(512), np.log(16384), size=1000)).astype(int)
