@@ -1,0 +1,120 @@
+"""Host-to-host streaming pipeline: raw int16 DAC reads in, homopolymer spans out.
+
+One batch = many reads packed back to back.  Per batch the device runs
+``cf_normalize -> cf_infer -> cf_postprocess -> cf_spans``; only 2 B/sample go up and two short
+run-boundary lists come down.  Batches are double-buffered: the H2D copy of batch k+1 (copy stream,
+pinned staging) overlaps the kernels of batch k (compute stream), and the host-side span assembly of
+batch k-1 overlaps both.  This is the "secondary" (PCIe-inclusive) rate of SURVEY.md 8d; it is never
+bench.py's ``value``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .batching import spans_from_runs
+from .infer import WINDOW_SIZE, padding_size_for
+
+
+class _Ticket(object):
+    __slots__ = ("lengths", "s_off", "starts", "ends", "counts", "counts_h", "done", "max_runs", "labels", "keep")
+
+
+class ReadPipeline(object):
+    def __init__(self, engine, max_samples_per_batch, threshold=0.5, min_run=15):
+        import torch
+        self.torch = torch
+        self.eng = engine
+        self.dev = torch.device("cuda", engine.device)
+        self.threshold = float(threshold)
+        self.min_run = int(min_run)
+        self.compute = torch.cuda.Stream(self.dev)
+        self.copy = torch.cuda.Stream(self.dev)
+        self.cap = int(max_samples_per_batch)
+        # two pinned staging buffers (double buffering)
+        self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(2)]
+        self.stage_free = [torch.cuda.Event() for _ in range(2)]
+        self.k = 0
+
+    def submit(self, dac_reads):
+        """Launch one batch asynchronously; returns a ticket for ``collect``."""
+        torch = self.torch
+        lengths = np.array([len(r) for r in dac_reads], dtype=np.int64)
+        total = int(lengths.sum())
+        if total > self.cap:
+            raise ValueError("batch of %d samples exceeds max_samples_per_batch=%d" % (total, self.cap))
+        dac_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=dac_off[1:])
+        n_win = np.array([(int(n) + padding_size_for(int(n))) // WINDOW_SIZE for n in lengths], dtype=np.int64)
+        win_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
+        np.cumsum(n_win, out=win_off[1:])
+        slot = self.k & 1
+        self.k += 1
+        self.stage_free[slot].synchronize()                     # previous H2D out of this staging buffer is done
+        host = self.stage[slot].numpy()
+        for r, o in zip(dac_reads, dac_off[:-1]):
+            host[o:o + len(r)] = r
+        with torch.cuda.stream(self.copy):
+            d_dac = self.stage[slot][:total].to(self.dev, non_blocking=True)
+            d_doff = torch.from_numpy(dac_off).to(self.dev, non_blocking=True)
+            d_woff = torch.from_numpy(win_off).to(self.dev, non_blocking=True)
+            d_soff = torch.from_numpy(win_off * WINDOW_SIZE).to(self.dev, non_blocking=True)
+            d_len = torch.from_numpy(lengths).to(self.dev, non_blocking=True)
+            self.stage_free[slot].record(self.copy)
+            copied = torch.cuda.Event()
+            copied.record(self.copy)
+        t = _Ticket()
+        with torch.cuda.stream(self.compute):
+            self.compute.wait_event(copied)
+            n_windows = int(win_off[-1])
+            x = torch.empty(n_windows, WINDOW_SIZE, dtype=torch.float32, device=self.dev)
+            self.eng.normalize_device(d_dac, d_doff, d_woff, out=x, stream=self.compute)
+            probs = self.eng.infer_device(x, stream=self.compute)
+            labels = self.eng.postprocess_device(probs, d_soff, d_len, threshold=self.threshold, min_run=self.min_run,
+                                                 stream=self.compute)
+            max_runs = n_windows * WINDOW_SIZE // self.min_run + 16
+            t.starts = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
+            t.ends = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
+            t.counts = torch.empty(2, dtype=torch.int64, device=self.dev)
+            N.check(self.eng._lib.cf_spans(self.eng._handle, C.c_void_p(labels.data_ptr()), int(labels.numel()), max_runs,
+                                           C.c_void_p(t.starts.data_ptr()), C.c_void_p(t.ends.data_ptr()),
+                                           C.c_void_p(t.counts.data_ptr()), C.c_void_p(self.compute.cuda_stream)))
+            t.counts_h = t.counts.to("cpu", non_blocking=True)
+            t.done = torch.cuda.Event()
+            t.done.record(self.compute)
+        t.lengths, t.s_off, t.max_runs, t.labels = lengths, win_off * WINDOW_SIZE, max_runs, labels
+        t.keep = (d_dac, d_doff, d_woff, d_soff, d_len, x, probs)   # keep device buffers alive until collected
+        return t
+
+    def collect(self, t, as_lists=True):
+        """Wait for a batch and assemble [(spans, read length)] in input order.
+
+        ``as_lists=False`` skips the per-read Python lists and returns the span table as arrays
+        ``(read_index, start - 11, end + 16, read_lengths)`` (what a high-rate consumer wants)."""
+        t.done.synchronize()
+        n_s, n_e = (int(v) for v in t.counts_h.tolist())
+        if n_s != n_e or n_s > t.max_runs:
+            raise RuntimeError("cf_spans returned %d starts / %d ends (capacity %d)" % (n_s, n_e, t.max_runs))
+        with self.torch.cuda.stream(self.compute):
+            starts = np.sort(t.starts[:n_s].cpu().numpy())
+            ends = np.sort(t.ends[:n_e].cpu().numpy())
+        t.keep = None
+        if not as_lists:
+            read_of = np.searchsorted(t.s_off, starts, side="right") - 1
+            base = t.s_off[read_of]
+            return read_of, starts - base - 11, ends - base + 16, t.lengths
+        spans = spans_from_runs(starts, ends, t.s_off, len(t.lengths))
+        return [(spans[i], int(t.lengths[i])) for i in range(len(t.lengths))]
+
+    def run(self, batches, as_lists=True):
+        """Iterate over batches (lists of int16 reads) with one batch in flight ahead; yields results."""
+        pending = None
+        for b in batches:
+            ticket = self.submit(b)
+            if pending is not None:
+                yield self.collect(pending, as_lists)
+            pending = ticket
+        if pending is not None:
+            yield self.collect(pending, as_lists)

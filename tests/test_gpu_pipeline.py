@@ -229,3 +229,23 @@ def test_save_network_round_trip(model, tmp_path, hp):
     x = np.random.default_rng(0).normal(size=(20, 35, 1))
     assert np.array_equal(m2.infer(x), model.infer(x))
     m2.engine.close()
+
+
+def test_streaming_pipeline_matches_oracle(model, ckpt_weights):
+    """ReadPipeline: pinned int16 DAC in -> spans out, double-buffered; results equal the per-read oracle."""
+    from catfish_amd.pipeline import ReadPipeline
+    lens = [4096, 700, 35, 5000, 36, 2048, 999, 1234]
+    dacs = [oracle.synthetic_dac(1, n, seed=300 + i)[0] for i, n in enumerate(lens)]
+    pipe = ReadPipeline(model.engine, max_samples_per_batch=12000)
+    batches = [dacs[0:3], dacs[3:5], dacs[5:8]]
+    got = [r for res in pipe.run(batches) for r in res]
+    for d, g in zip(dacs, got):
+        w_spans, w_len, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
+        assert g == (w_spans, w_len)
+    # array form carries the same information
+    t = pipe.submit(batches[0])
+    read_of, s, e, ln = pipe.collect(t, as_lists=False)
+    flat = [[int(a), int(b)] for a, b in zip(s, e)]
+    assert flat == [sp for spans, _ in got[:3] for sp in spans] and list(ln) == lens[:3]
+    with pytest.raises(ValueError):
+        pipe.submit([np.zeros(20000, np.int16)])
