@@ -44,6 +44,7 @@ class RNN(object):
         # MI355X-specific knobs (not in the reference)
         self.device = int(kwargs.get("device", 0))
         self.max_windows_per_pass = int(kwargs.get("max_windows_per_pass", DEFAULT_MAX_WINDOWS))
+        self.precision = kwargs.get("precision", "fp32")      # "fp32" (exact) | "bf16x3" | "bf16"
 
         self.weights = None
         self.engine = None
@@ -83,7 +84,8 @@ class RNN(object):
         self._engine_stale = False
         self.engine = HipEngine(weights, layer_size=self.layer_size, n_layers=self.n_layers,
                                 layer_size_res=self.layer_size_res_, n_layers_res=self.n_layers_res_,
-                                device=self.device, max_windows_per_pass=self.max_windows_per_pass)
+                                device=self.device, max_windows_per_pass=self.max_windows_per_pass,
+                                precision=self.precision)
 
     def _initial_weights(self, seed=None):
         """TF default initialisers: glorot-uniform kernels, zero biases,
