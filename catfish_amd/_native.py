@@ -19,7 +19,7 @@ CF_ERR_INVALID = -1
 CF_ERR_HIP = -2
 CF_ERR_NOMEM = -3
 CF_WINDOW = 35
-CF_PROF_SLOTS = 8
+CF_PROF_SLOTS = 12
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 _f32p = C.POINTER(C.c_float)
@@ -29,7 +29,7 @@ class cf_hparams(C.Structure):
     _fields_ = [("layer_size", C.c_int32), ("n_layers", C.c_int32),
                 ("layer_size_res", C.c_int32), ("n_layers_res", C.c_int32),
                 ("window", C.c_int32), ("bn_epsilon", C.c_float),
-                ("max_windows_per_pass", C.c_int64), ("n_streams", C.c_int32), ("precision", C.c_int32)]
+                ("max_windows_per_pass", C.c_int64), ("n_streams", C.c_int32), ("precision", C.c_int32), ("fuse_layers", C.c_int32)]
 
 
 class cf_conv_bn(C.Structure):

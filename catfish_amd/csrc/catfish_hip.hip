@@ -214,41 +214,31 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
 // LAST = true fuses the dense(128->1) partial dot (rnn_class.py:179) instead
 // of writing h.
 // ------------------------------------------------------------------------------------------
+template <int CIN>
+__device__ __forceinline__ void gru_stage_weights(float* lds, const float* __restrict__ wpack, int dir) {
+    constexpr int PACK = gru_pack_floats(CIN);
+    const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i = threadIdx.x; i < PACK / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// One tile (16 windows) of one direction of one layer: the whole 35-step recurrence.
 template <int CIN, bool LAST>
-__global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restrict__ wpack,  // [2][gru_pack_floats(CIN)]
-                                                           const f32x4* __restrict__ X,      // [tile][t][CIN/16][lane]
-                                                           f32x4* __restrict__ Y,            // [tile][t][8][lane]
-                                                           float* __restrict__ P,            // [2][tile][t][16]
-                                                           int n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, int tile, const f32x4* __restrict__ X,
+                                         f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles) {
     constexpr int KGX = CIN / 16;   // f32x4 registers of x per lane and step
     constexpr int KSX = CIN / 4;    // k-steps of the x part
-    constexpr int PACK = gru_pack_floats(CIN);
     constexpr int XN4 = gru_x_floats(CIN) / 4;        // region sizes in f32x4 units
     constexpr int HG4 = gru_hg_floats() / 4;
     constexpr int BIAS = gru_bias_off(CIN);
     constexpr int DENSE = gru_dense_off(CIN);
-
-    const int dir = blockIdx.y;
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < PACK / 4; i += CF_GRU_WAVES * 64) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4;
-    if (CF_ABLATE & 8) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_sleep(100); }
-    if (CF_ABLATE & 16) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_setprio(1); }
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;     // + (ks*3+g)*64
     const f32x4* WG = WX + XN4;                                        // + (ks*2+g)*64
     const f32x4* WC = WG + HG4;                                        // + ks*64
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;  // + mo*4
     const f32x4* D4 = reinterpret_cast<const f32x4*>(lds + DENSE) + q; // + m*4
-
-    for (int tile = blockIdx.x * CF_GRU_WAVES + wave; tile < n_tiles; tile += gridDim.x * CF_GRU_WAVES) {
+    {
         f32x4 h[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // GRUCellZeroState
         f32x4 xc[KGX];
         {
@@ -364,6 +354,116 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+}
+
+template <int CIN, bool LAST>
+__global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restrict__ wpack,  // [2][gru_pack_floats(CIN)]
+                                                           const f32x4* __restrict__ X,      // [tile][t][CIN/16][lane]
+                                                           f32x4* __restrict__ Y,            // [tile][t][8][lane]
+                                                           float* __restrict__ P,            // [2][tile][t][16]
+                                                           int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int dir = blockIdx.y;
+    gru_stage_weights<CIN>(lds, wpack, dir);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (CF_ABLATE & 8) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_sleep(100); }
+    if (CF_ABLATE & 16) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_setprio(1); }
+    for (int tile = blockIdx.x * CF_GRU_WAVES + wave; tile < n_tiles; tile += gridDim.x * CF_GRU_WAVES)
+        gru_tile<CIN, LAST>(lds, lane, dir, tile, X, Y, P, n_tiles);
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2b: all biGRU layers in ONE launch.  A separate launch per layer leaves CUs idle in every
+// layer's last round (1888 tiles per direction on 1024 SIMDs = 3.69 rounds -> 7.8 % lost per launch).
+// Here workgroups are ordered layer-major (a pool per layer and direction that pulls 8-tile groups from a
+// queue), so the first groups of layer l+1 start on the CUs that layer l's tail frees.  A group of layer
+// l > 0 waits for both directions of the same group of layer l-1 through agent-scope flags
+// (release/acquire exactly as cdna_hip_programming.md Guideline 16).  Every wait is bounded: on a
+// timeout the workgroup records an error code and carries on, so the grid always drains.
+// Progress argument: workgroups are dispatched in index order per XCD, so when a waiting workgroup holds
+// a CU every workgroup of the previous layer has already been dispatched and none of those ever waits on
+// a later one.
+// ------------------------------------------------------------------------------------------
+struct cf_fused_args {
+    const float* w[3];       // packed weights of layer 0..2, [2 dirs]
+    const f32x4* x0;         // layer-0 input (conv output / embedding), fragment layout
+    f32x4* y[2];             // layer outputs (layer l writes y[l & 1])
+    float* p;                // dense partials
+    unsigned* flags;         // [n_layers][groups][2] completion flags, then [n_layers][2] queue heads; zeroed before the launch
+    int lds_floats;          // floats of dynamic LDS holding weights (one broadcast word follows)
+    unsigned* err;           // [1], zeroed before the launch; != 0 after a wait timed out
+    int n_tiles;
+    int groups;              // ceil(n_tiles / 8)
+    int n_layers;            // 1..3
+    int cin0;                // 32 (ResNetRNN) or 16 (plain RNN)
+};
+
+__device__ __forceinline__ bool cf_wait_flag(unsigned* flag) {
+    for (int it = 0; it < 1000000; ++it) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return false;
+}
+
+// A workgroup serves ONE (layer, direction): it stages those weights once, then pulls 8-tile groups from
+// that (layer, direction)'s queue until it is empty.
+template <int CIN, bool LAST>
+__device__ __forceinline__ void gru_fused_worker(float* lds, const cf_fused_args& a, int layer, int dir) {
+    const f32x4* X = layer == 0 ? a.x0 : a.y[(layer - 1) & 1];
+    f32x4* Y = a.y[layer & 1];
+    gru_stage_weights<CIN>(lds, a.w[layer], dir);
+    volatile int* slot = reinterpret_cast<volatile int*>(lds + a.lds_floats);   // broadcast word behind the weights
+    unsigned* queue = a.flags + (size_t)a.n_layers * a.groups * 2 + layer * 2 + dir;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // A pool member serves at most `groups` groups before it sees the queue empty: the loop is bounded by
+    // construction (a plain `for (;;)` with a break in the middle hung on gfx950 / ROCm 7.2).
+    int group = 0;
+    for (int iter = 0; iter <= a.groups && group < a.groups; ++iter) {
+        if (threadIdx.x == 0) {
+            const int g = (int)__hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (layer > 0 && g < a.groups) {
+                // consumer side: ONE lane polls relaxed, then ONE agent-scope acquire
+                unsigned* f = a.flags + ((size_t)(layer - 1) * a.groups + g) * 2;
+                if (!cf_wait_flag(f) || !cf_wait_flag(f + 1)) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *slot = g;
+        }
+        __syncthreads();
+        group = *slot;                                   // the same value in every thread
+        if (group < a.groups) {
+            const int tile = group * 8 + wave;
+            if (tile < a.n_tiles) gru_tile<CIN, LAST>(lds, lane, dir, tile, X, Y, a.p, a.n_tiles);
+            // producer side: every storing wave drains, barrier, ONE lane releases at agent scope, then the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!LAST && threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.flags + ((size_t)layer * a.groups + group) * 2 + dir, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gru_fused_kernel(cf_fused_args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int per_layer = gridDim.x / a.n_layers;          // workgroups per layer, directions interleaved
+    const int layer = blockIdx.x / per_layer;
+    const int dir = (blockIdx.x - layer * per_layer) & 1;
+    const bool last = layer == a.n_layers - 1;
+    if (layer == 0) {
+        if (a.cin0 == 16) { if (last) gru_fused_worker<16, true>(lds, a, layer, dir); else gru_fused_worker<16, false>(lds, a, layer, dir); }
+        else { if (last) gru_fused_worker<32, true>(lds, a, layer, dir); else gru_fused_worker<32, false>(lds, a, layer, dir); }
+    } else {
+        if (last) gru_fused_worker<128, true>(lds, a, layer, dir); else gru_fused_worker<128, false>(lds, a, layer, dir);
     }
 }
 
@@ -555,9 +655,10 @@ static int fail(int code, const std::string& msg) {
             return fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
-enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_NORM };
+enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_NORM, SLOT_GRU_FUSED };
 static const char* k_slot_names[CF_PROF_SLOTS] = {"res_block_first", "res_block",      "gru_layer_first", "gru_layer_mid",
-                                                  "gru_layer_last",  "head",           "postprocess",     "normalize"};
+                                                  "gru_layer_last",  "head",           "postprocess",     "normalize",       "gru_fused",
+                                                  "unused",          "unused",         "unused"};
 
 struct cf_model {
     cf_hparams hp;
@@ -580,11 +681,16 @@ struct cf_model {
         float* d_a[2] = {nullptr, nullptr};   // conv ping-pong, F = 32
         float* d_y[2] = {nullptr, nullptr};   // GRU layer outputs ping-pong, F = 128
         float* d_p = nullptr;                 // dense partials [2][tiles][35][16]
+        unsigned* d_flags = nullptr;          // fused launch: [n_layers][groups][2] completion flags
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
         int64_t last_windows = 0;             // windows of the last pass (debug hook)
     };
     std::vector<Slot> slots;
+    int fuse = 0;                             // all GRU layers in one launch (fp32 path, n_layers <= 3): 0 never, 1 always,
+                                              // 2 auto = only for passes of >= 6 rounds, where the dynamic queues pay
+    unsigned* h_err = nullptr;                // host-mapped: set by a fused launch whose bounded wait timed out (sticky)
+    unsigned* d_err = nullptr;                // device view of h_err
     hipEvent_t fork = nullptr;
     int64_t ws_bytes = 0;
     // profiling
@@ -735,9 +841,11 @@ extern "C" void cf_model_destroy(cf_model* m) {
     for (auto& sl : m->slots) {
         for (int i = 0; i < 2; ++i) { if (sl.d_a[i]) (void)hipFree(sl.d_a[i]); if (sl.d_y[i]) (void)hipFree(sl.d_y[i]); }
         if (sl.d_p) (void)hipFree(sl.d_p);
+        if (sl.d_flags) (void)hipFree(sl.d_flags);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (m->h_err) (void)hipHostFree(m->h_err);
     if (m->fork) (void)hipEventDestroy(m->fork);
     for (auto& e : m->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : m->ev_pool) (void)hipEventDestroy(e);
@@ -831,10 +939,15 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
             for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&sl.d_a[i], a_bytes);
             for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc((void**)&sl.d_y[i], y_bytes);
             if (e == hipSuccess) e = hipMalloc((void**)&sl.d_p, p_bytes);
+            if (e == hipSuccess) e = hipMalloc((void**)&sl.d_flags, (size_t)3 * ((m->cap_tiles + 7) / 8) * 2 * sizeof(unsigned) + 64);
             if (e == hipSuccess && n_slots > 1) e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
             if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
         }
         if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_err, sizeof(unsigned), hipHostMallocMapped);
+        if (e == hipSuccess) { *m->h_err = 0u; e = hipHostGetDevicePointer((void**)&m->d_err, m->h_err, 0); }
+        m->fuse = (m->np == 0 && hp->n_layers <= 3 && hp->fuse_layers >= 0) ? (hp->fuse_layers > 0 ? 1 : 2) : 0;
+        if (getenv("CATFISH_FUSE") && m->fuse) m->fuse = atoi(getenv("CATFISH_FUSE")) != 0 ? 1 : 0;   // A/B knob for tools/
         if (e != hipSuccess) rc = fail(CF_ERR_NOMEM, std::string("workspace allocation: ") + hipGetErrorString(e));
         m->ws_bytes = (int64_t)n_slots * (int64_t)(2 * a_bytes + 2 * y_bytes + p_bytes);
     }
@@ -848,6 +961,7 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_layer_kernel<32, true>, gru_pack_floats(32) * 4);
         optin((const void*)gru_layer_kernel<128, false>, gru_pack_floats(128) * 4);
         optin((const void*)gru_layer_kernel<128, true>, gru_pack_floats(128) * 4);
+        optin((const void*)gru_fused_kernel, gru_pack_floats(128) * 4 + 16);
         optin((const void*)gru_layer_bf16_kernel<32, false, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<32, true, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<128, false, 1>, gb_pack_bytes(128, 1));
@@ -980,7 +1094,30 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     }
     const float* cur = m->hp.n_layers_res == 0 ? sl.d_a[0] : sl.d_a[(m->hp.n_layers_res - 1) & 1];
     // GRU layers
-    for (int l = 0; l < m->hp.n_layers; ++l) {
+    const bool fuse_now = m->fuse == 1 || (m->fuse == 2 && (n_tiles + 7) / 8 >= 6 * std::max(1, m->n_cu / 2));
+    if (fuse_now) {
+        cf_fused_args a;
+        for (int l = 0; l < 3; ++l) a.w[l] = l < m->hp.n_layers ? m->d_gru[l] : nullptr;
+        a.x0 = reinterpret_cast<const f32x4*>(cur);
+        a.y[0] = reinterpret_cast<f32x4*>(sl.d_y[0]);
+        a.y[1] = reinterpret_cast<f32x4*>(sl.d_y[1]);
+        a.p = sl.d_p;
+        a.flags = sl.d_flags;
+        a.err = m->d_err;
+        a.n_tiles = n_tiles;
+        a.groups = (n_tiles + 7) / 8;
+        a.n_layers = m->hp.n_layers;
+        a.cin0 = m->hp.n_layers_res == 0 ? 16 : CF_C;
+        HIP_TRY(hipMemsetAsync(sl.d_flags, 0, ((size_t)a.n_layers * a.groups * 2 + (size_t)a.n_layers * 2) * sizeof(unsigned), s));
+        if ((rc = prof_begin(m, SLOT_GRU_FUSED, s, &pi)) != CF_OK) return rc;
+        a.lds_floats = m->hp.n_layers > 1 ? gru_pack_floats(128) : gru_pack_floats(a.cin0);
+        const int lds_bytes = a.lds_floats * 4 + 16;
+        const int pool = std::min(a.groups, std::max(1, m->n_cu / 2)) * 2;     // workgroups per layer (both directions)
+        hipLaunchKernelGGL(gru_fused_kernel, dim3((unsigned)(a.n_layers * pool)), dim3(512), lds_bytes, s, a);
+        HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+    }
+    for (int l = 0; l < (fuse_now ? 0 : m->hp.n_layers); ++l) {
         const bool last = l == m->hp.n_layers - 1;
         float* y = sl.d_y[l & 1];
         if (m->np > 0) {
@@ -1015,6 +1152,9 @@ extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* p
     if (n_windows < 0) return fail(CF_ERR_INVALID, "cf_infer: negative n_windows");
     if (n_windows == 0) return CF_OK;
     if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer: null buffer");
+    if (m->h_err && *m->h_err)
+        return fail(CF_ERR_HIP, "an earlier fused GRU launch timed out waiting for a producer workgroup; its results are invalid "
+                                "(create the model with fuse_layers = -1)");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_slots = (int)m->slots.size();
@@ -1070,6 +1210,7 @@ extern "C" int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, flo
     if ((e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
     if (rc == CF_OK) rc = cf_infer(m, dx, n_windows, dp, nullptr);
     if (rc == CF_OK && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
+    if (rc == CF_OK && m->h_err && *m->h_err) rc = fail(CF_ERR_HIP, "fused GRU launch timed out waiting for a producer workgroup");
     if (rc == CF_OK && (e = hipMemcpy(probs, dp, bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
     (void)hipFree(dx);
     (void)hipFree(dp);

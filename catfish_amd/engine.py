@@ -20,7 +20,7 @@ class HipEngine(object):
 
     def __init__(self, weights, layer_size=64, n_layers=3, layer_size_res=32, n_layers_res=2,
                  device=0, max_windows_per_pass=DEFAULT_MAX_WINDOWS, bn_epsilon=1e-3, n_streams=0,
-                 precision="fp32"):
+                 precision="fp32", fuse_layers=None):
         self._lib = N.lib()
         self._handle = C.c_void_p()
         if precision not in N.PRECISIONS:
@@ -28,7 +28,7 @@ class HipEngine(object):
         self.precision = precision
         hp = N.cf_hparams(int(layer_size), int(n_layers), int(layer_size_res), int(n_layers_res),
                           WINDOW, float(bn_epsilon), int(max_windows_per_pass), int(n_streams),
-                          N.PRECISIONS[precision])
+                          N.PRECISIONS[precision], 0 if fuse_layers is None else (1 if fuse_layers else -1))
         w, keep = N.build_weight_structs(weights, int(n_layers), int(n_layers_res))
         N.check(self._lib.cf_model_create(C.byref(w), C.byref(hp), int(device), C.byref(self._handle)))
         del keep  # the library copied/re-tiled everything

@@ -56,6 +56,9 @@ typedef struct cf_hparams {
     int32_t n_streams;           /* scratch slots + internal streams that overlap the
                                     sub-batches of one call (0 = default 1 = none)       */
     int32_t precision;           /* CF_PREC_*                                          */
+    int32_t fuse_layers;         /* all biGRU layers in ONE launch with dynamic tile queues (fp32,
+                                    n_layers <= 3): 0 = auto (only passes of >= 6 full-chip rounds,
+                                    where it measures +5 %), 1 = always, -1 = never          */
 } cf_hparams;
 
 /* One conv1d + batch_normalization pair, TF layout
@@ -147,7 +150,7 @@ int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets,
  * events around each kernel; cf_profile_read synchronises and returns, for
  * kernel slot k, the accumulated milliseconds and launch count since the
  * last cf_profile_reset. */
-#define CF_PROF_SLOTS 8
+#define CF_PROF_SLOTS 12
 int cf_profile_enable(cf_model* m, int on);
 int cf_profile_reset(cf_model* m);
 int cf_profile_read(cf_model* m, double ms[CF_PROF_SLOTS], int64_t launches[CF_PROF_SLOTS]);

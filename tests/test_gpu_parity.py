@@ -107,3 +107,21 @@ def test_bf16_modes_ragged_random_weights(precision, tol, n_windows):
     err = np.abs(got - want).max()
     assert np.isfinite(got).all()
     assert err < tol, err
+
+
+@pytest.mark.parametrize("n_windows", [16, 129, 2000])
+def test_fused_single_launch_matches_per_layer_launches(ckpt_weights, n_windows):
+    """fuse_layers=True: all biGRU layers in one launch (agent-scope flags + dynamic queues) is bit-identical
+    to one launch per layer; repeated to catch a stale hand-off."""
+    from catfish_amd.engine import HipEngine
+    rng = np.random.default_rng(n_windows)
+    x = rng.normal(0, 1.5, size=(n_windows, 35)).astype(np.float32)
+    a = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096, fuse_layers=False)
+    b = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096, fuse_layers=True)
+    try:
+        ref = a.infer_host(x)
+        for _ in range(5):
+            assert np.array_equal(b.infer_host(x), ref)
+        assert np.array_equal(b.debug_stage(3, min(n_windows, 64)), a.debug_stage(3, min(n_windows, 64)))
+    finally:
+        a.close(); b.close()

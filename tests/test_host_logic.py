@@ -195,7 +195,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared <= exported
     lib = _native.lib()
     assert b"gfx950" in lib.cf_version()
-    assert lib.cf_profile_slot_name(3) == b"gru_layer_mid"
+    assert lib.cf_profile_slot_name(3) == b"gru_layer_mid" and lib.cf_profile_slot_name(8) == b"gru_fused"
 
 
 def test_product_never_imports_oracle():
