@@ -117,8 +117,13 @@ class TFOptimizer(object):
             raise ValueError("Given optimizer choice is not known. Choose 'Adam' or 'RMSProp'.")
         self.choice = choice
         self.lr = float(lr)
+        self.keep_grads = False      # graph mode: gradients live in the captured pool and are overwritten on replay
         self.params = params
-        self.t = 0
+        first = next(iter(params.values()))
+        # step counter as a DEVICE tensor so that the bias correction is computed by captured ops (hipGraph replay)
+        self.t = torch.zeros((), dtype=torch.float64, device=first.device)
+        self._b1 = torch.tensor(0.9, dtype=torch.float64, device=first.device)      # created outside any capture
+        self._b2 = torch.tensor(0.999, dtype=torch.float64, device=first.device)
         if choice == "Adam":
             self.m = {k: torch.zeros_like(v) for k, v in params.items()}
             self.v = {k: torch.zeros_like(v) for k, v in params.items()}
@@ -128,28 +133,37 @@ class TFOptimizer(object):
 
     def step(self):
         torch = self.torch
-        self.t += 1
         with torch.no_grad():
+            self.t.add_(1.0)
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            if self.choice == "Adam":
+                lr_t = self.lr * torch.sqrt(1.0 - torch.pow(self._b2, self.t)) / (1.0 - torch.pow(self._b1, self.t))
             for k, p in self.params.items():
                 g = p.grad
                 if g is None:
                     continue
                 if self.choice == "Adam":
-                    b1, b2, eps = 0.9, 0.999, 1e-8
                     self.m[k].mul_(b1).add_(g, alpha=1 - b1)
                     self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
-                    lr_t = self.lr * np.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t)
-                    p.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + eps))
+                    p.sub_(lr_t.to(p.dtype) * self.m[k] / (self.v[k].sqrt() + eps))
                 else:
                     decay, eps = 0.9, 1e-10
                     self.ms[k].mul_(decay).addcmul_(g, g, value=1 - decay)
                     p.sub_(self.lr * g / torch.sqrt(self.ms[k] + eps))         # momentum = 0
-                p.grad = None
+                if not self.keep_grads:
+                    p.grad = None
 
 
 class Trainer(object):
+    """One training step = forward + backward + optimizer update.
+
+    On a GPU the whole step (thousands of tiny recurrent kernels) is launch-bound in eager mode, so it is
+    captured ONCE into a HIP graph (``torch.cuda.CUDAGraph``) and replayed per batch; batches are copied into
+    static input buffers.  Dropout inside the graph draws from torch's default (graph-safe) CUDA generator.
+    """
+
     def __init__(self, weights, n_layers, n_layers_res, optimizer_choice, learning_rate, keep_prob, device=None,
-                 seed=None):
+                 seed=None, use_graph=None):
         import torch
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
@@ -160,9 +174,45 @@ class Trainer(object):
         if seed is not None:
             self.gen.manual_seed(int(seed))
         self.last_loss = None
+        self.use_graph = (self.net.device.type == "cuda") if use_graph is None else bool(use_graph)
+        self._graph = None
+        self._static = None
+        if seed is not None and self.net.device.type == "cuda":
+            torch.cuda.manual_seed(int(seed))
+
+    def _capture(self, x, y):
+        torch = self.torch_mod = __import__("torch")
+        sx = torch.zeros(tuple(np.asarray(x).reshape(-1, 35).shape), dtype=self.net.dtype, device=self.net.device)
+        sy = torch.zeros_like(sx)
+        self.opt.keep_grads = True
+        side = torch.cuda.Stream(self.net.device)
+        side.wait_stream(torch.cuda.current_stream(self.net.device))
+        with torch.cuda.stream(side):                       # warm-up off the capture stream (allocator, lazy init)
+            for _ in range(2):
+                loss = self.net.loss(sx, sy, self.keep_prob, None)
+                loss.backward()
+                for p in self.net.trainable().values():
+                    p.grad = None
+        torch.cuda.current_stream(self.net.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            sloss = self.net.loss(sx, sy, self.keep_prob, None)
+            sloss.backward()
+            self.opt.step()
+        self._graph, self._static = g, (sx, sy, sloss)
 
     def train_step(self, x, y, keep_prob=None):
         kp = self.keep_prob if keep_prob is None else keep_prob
+        if self.use_graph and kp == self.keep_prob:
+            torch = __import__("torch")
+            if self._graph is None or tuple(self._static[0].shape) != tuple(np.asarray(x).reshape(-1, 35).shape):
+                self._capture(x, y)          # first batch, or a new batch size: (re)capture the step
+            sx, sy, sloss = self._static
+            sx.copy_(torch.as_tensor(np.asarray(x), dtype=self.net.dtype).reshape(sx.shape), non_blocking=True)
+            sy.copy_(torch.as_tensor(np.asarray(y), dtype=self.net.dtype).reshape(sy.shape), non_blocking=True)
+            self._graph.replay()
+            self.last_loss = float(sloss.detach())
+            return self.last_loss
         loss = self.net.loss(x, y, kp, self.gen)
         loss.backward()
         self.opt.step()
