@@ -45,7 +45,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CF_ABLATE
 #define CF_ABLATE 0
 #endif
-#define CF_GRU_WAVES ((CF_ABLATE & 4) ? 4 : 8)
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -369,9 +368,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (CF_ABLATE & 8) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_sleep(100); }
-    if (CF_ABLATE & 16) { if (wave >= CF_GRU_WAVES / 2) __builtin_amdgcn_s_setprio(1); }
-    for (int tile = blockIdx.x * CF_GRU_WAVES + wave; tile < n_tiles; tile += gridDim.x * CF_GRU_WAVES)
+    const int nwaves = blockDim.x >> 6;
+    for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves)
         gru_tile<CIN, LAST>(lds, lane, dir, tile, X, Y, P, n_tiles);
 }
 
@@ -997,9 +995,18 @@ static int prof_end(cf_model* m, hipStream_t s, size_t idx) {
     return CF_OK;
 }
 
+// Waves per workgroup: 8 (two per SIMD) when the pass fills the chip; fewer for small calls (a single read is
+// 8 tiles x 2 directions) so that the tiles spread over more CUs instead of sharing SIMDs -- the 35-step
+// chain is latency-bound there.
+static int pick_waves(int n_tile_tasks, int n_cu) {
+    int w = (n_tile_tasks + n_cu - 1) / n_cu;
+    return w <= 1 ? 1 : (w <= 2 ? 2 : (w <= 4 ? 4 : 8));
+}
+
 template <int CIN, bool LAST>
 static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
-    const int groups = (n_tiles + CF_GRU_WAVES - 1) / CF_GRU_WAVES;   // one workgroup pass = one tile per wave
+    const int waves = (CF_ABLATE & 4) ? 4 : pick_waves(2 * n_tiles, m->n_cu);
+    const int groups = (n_tiles + waves - 1) / waves;             // one workgroup pass = one tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;            // persistent: half the CUs per direction
     constexpr int lds_bytes = gru_pack_floats(CIN) * 4;
     if (lds_bytes <= 80 * 1024) per_dir *= 2;                   // two workgroups fit per CU
@@ -1007,7 +1014,7 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
     if (rc != CF_OK) return rc;
-    hipLaunchKernelGGL((gru_layer_kernel<CIN, LAST>), dim3(gx, 2), dim3(CF_GRU_WAVES * 64), lds_bytes, s, wpack,
+    hipLaunchKernelGGL((gru_layer_kernel<CIN, LAST>), dim3(gx, 2), dim3(waves * 64), lds_bytes, s, wpack,
                        reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
@@ -1015,7 +1022,8 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
 
 template <int CIN, bool LAST, int NP>
 static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float* Y, float* P, int n_tiles32, hipStream_t s, int slot) {
-    const int groups = (n_tiles32 + 7) / 8;                      // one workgroup pass = 8 tiles of 32 windows
+    const int waves = pick_waves(2 * n_tiles32, m->n_cu);
+    const int groups = (n_tiles32 + waves - 1) / waves;           // one workgroup pass = one 32-window tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;
     constexpr int lds_bytes = gb_pack_bytes(CIN, NP);
     if (lds_bytes <= 80 * 1024) per_dir *= 2;
@@ -1023,7 +1031,7 @@ static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
     if (rc != CF_OK) return rc;
-    hipLaunchKernelGGL((gru_layer_bf16_kernel<CIN, LAST, NP>), dim3(gx, 2), dim3(512), lds_bytes, s, wpack,
+    hipLaunchKernelGGL((gru_layer_bf16_kernel<CIN, LAST, NP>), dim3(gx, 2), dim3(waves * 64), lds_bytes, s, wpack,
                        reinterpret_cast<const bf16x8*>(X), reinterpret_cast<bf16x8*>(Y), P, n_tiles32);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
@@ -1045,7 +1053,8 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     int rc;
     size_t pi = 0;
     // residual blocks
-    const int res_grid = std::min((n_tiles + 3) / 4, m->n_cu * 4);
+    const int res_waves = pick_waves(n_tiles, m->n_cu * 2) > 4 ? 4 : pick_waves(n_tiles, m->n_cu * 2);
+    const int res_grid = std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
     for (int b = 0; b < m->hp.n_layers_res; ++b) {
         float* dst = sl.d_a[b & 1];
         if (m->np > 0) {
@@ -1073,12 +1082,12 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         } else if (b == 0) {
             if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = (res_pack_floats(true) + 4 * CF_TILE * CF_T) * 4;
-            hipLaunchKernelGGL((res_block_kernel<true>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[0], x,
+            hipLaunchKernelGGL((res_block_kernel<true>), dim3(res_grid), dim3(res_waves * 64), lds_bytes, s, m->d_res[0], x,
                                (const f32x4*)nullptr, reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         } else {
             if ((rc = prof_begin(m, SLOT_RES, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = res_pack_floats(false) * 4;
-            hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(256), lds_bytes, s, m->d_res[b], (const float*)nullptr,
+            hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(res_waves * 64), lds_bytes, s, m->d_res[b], (const float*)nullptr,
                                reinterpret_cast<const f32x4*>(sl.d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
         }
         HIP_TRY(hipGetLastError());

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < PACK / 16; i += 512) dst[i] = src[i];
+        for (int i = threadIdx.x; i < PACK / 16; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
     const f32x4* BI = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_bias_off(CIN, NP)) + hh * 4;
     const f32x4* DW = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_dense_off(CIN, NP)) + hh * 4;
 
-    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+    const int nwaves = blockDim.x >> 6;
+    for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves) {
         f32x16 h[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
