@@ -222,9 +222,12 @@ __device__ __forceinline__ void gru_stage_weights(float* lds, const float* __res
 }
 
 // One tile (16 windows) of one direction of one layer: the whole 35-step recurrence.
-template <int CIN, bool LAST>
+// STASH (training forward): also write the activated gates r, u and the candidate c of every step to
+// S[tile][t][dir][12][lane] (r = 0..3, u = 4..7, c = 8..11) for the backward pass.
+template <int CIN, bool LAST, bool STASH = false>
 __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, int tile, const f32x4* __restrict__ X,
-                                         f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles) {
+                                         f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
+                                         f32x4* __restrict__ S = nullptr) {
     constexpr int KGX = CIN / 16;   // f32x4 registers of x per lane and step
     constexpr int KSX = CIN / 4;    // k-steps of the x part
     constexpr int XN4 = gru_x_floats(CIN) / 4;        // region sizes in f32x4 units
@@ -310,7 +313,12 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rh[m][r] = (CF_ABLATE & 1) ? acc[m][r] * 0.001f : cf_sigmoid_pre(acc[m][r]) * h[m][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (CF_ABLATE & 1) { rh[m][r] = acc[m][r] * 0.001f; continue; }
+                    const float rv = cf_sigmoid_pre(acc[m][r]);
+                    rh[m][r] = rv * h[m][r];
+                    if constexpr (STASH) acc[m][r] = rv;
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
@@ -332,7 +340,13 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                     const float u = cf_sigmoid_pre(acc[4 + m][r]);
                     const float c = cf_tanh_pre(acc[8 + m][r]);
                     h[m][r] = fmaf(u, h[m][r] - c, c);
+                    if constexpr (STASH) { acc[4 + m][r] = u; acc[8 + m][r] = c; }
                 }
+            }
+            if constexpr (STASH) {
+                f32x4* sdst = S + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) sdst[j * 64] = acc[j];
             }
             if constexpr (!LAST) {
                 f32x4* dst = Y + (((int64_t)tile * CF_T + t) * 8 + dir * 4) * 64 + lane;
@@ -464,6 +478,8 @@ __global__ __launch_bounds__(512, 2) void gru_fused_kernel(cf_fused_args a) {
         if (last) gru_fused_worker<128, true>(lds, a, layer, dir); else gru_fused_worker<128, false>(lds, a, layer, dir);
     }
 }
+
+#include "gru_train.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1b: plain RNN type (no residual blocks, rnn_class.py:165-175 applied to the raw signal).
@@ -665,6 +681,8 @@ struct cf_model {
     std::vector<float*> d_res;   // per residual block packed weights
     std::vector<float*> d_gru;   // per layer packed weights [2 dirs]
     std::vector<int> gru_cin;
+    std::vector<float*> d_gru_bwd;  // per layer packed backward weights [2 dirs] (training, created on first update)
+    float dense_host[2 * CF_H] = {0};
     std::vector<char*> d_res_b;  // per residual block packed bf16 weights (precision != fp32)
     std::vector<char*> d_gru_b;  // per layer packed bf16 weights [2 dirs] (precision != fp32)
     int np = 0;                  // bf16 parts per operand: 0 = fp32 path, 1 = bf16, 2 = bf16x3
@@ -835,6 +853,7 @@ extern "C" void cf_model_destroy(cf_model* m) {
     for (float* p : m->d_res) if (p) (void)hipFree(p);
     for (float* p : m->d_gru) if (p) (void)hipFree(p);
     for (char* p : m->d_gru_b) if (p) (void)hipFree(p);
+    for (float* p : m->d_gru_bwd) if (p) (void)hipFree(p);
     for (char* p : m->d_res_b) if (p) (void)hipFree(p);
     for (auto& sl : m->slots) {
         for (int i = 0; i < 2; ++i) { if (sl.d_a[i]) (void)hipFree(sl.d_a[i]); if (sl.d_y[i]) (void)hipFree(sl.d_y[i]); }
@@ -920,6 +939,8 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         }
     }
     m->dense_bias = w->dense_bias[0];
+    memcpy(m->dense_host, w->dense_kernel, sizeof(m->dense_host));
+    m->d_gru_bwd.assign(hp->n_layers, nullptr);
     // workspace
     if (rc == CF_OK) {
         int64_t cap = hp->max_windows_per_pass > 0 ? hp->max_windows_per_pass : 32768;
@@ -960,6 +981,10 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_layer_kernel<128, false>, gru_pack_floats(128) * 4);
         optin((const void*)gru_layer_kernel<128, true>, gru_pack_floats(128) * 4);
         optin((const void*)gru_fused_kernel, gru_pack_floats(128) * 4 + 16);
+        optin((const void*)gru_train_fwd_kernel<32>, gru_pack_floats(32) * 4);
+        optin((const void*)gru_train_fwd_kernel<128>, gru_pack_floats(128) * 4);
+        optin((const void*)gru_train_bwd_kernel<32>, gtb_pack_floats(32) * 4);
+        optin((const void*)gru_train_bwd_kernel<128>, gtb_pack_floats(128) * 4);
         optin((const void*)gru_layer_bf16_kernel<32, false, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<32, true, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<128, false, 1>, gb_pack_bytes(128, 1));
@@ -1276,6 +1301,82 @@ extern "C" int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)n_reads), dim3(256), 0, s, dac, dac_offsets, win_offsets, x_out);
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
+}
+
+// ---- training support (BASELINE config 5) ------------------------------------------------
+static int train_layer_cin(const cf_model* m, int layer, int* cin) {
+    if (layer < 0 || layer >= m->hp.n_layers) return fail(CF_ERR_INVALID, "training: layer out of range");
+    if (m->np != 0 || m->hp.n_layers_res == 0) return fail(CF_ERR_INVALID, "training kernels need CF_PREC_FP32 and the ResNetRNN type");
+    *cin = layer == 0 ? CF_C : 2 * CF_H;
+    return CF_OK;
+}
+
+extern "C" int cf_model_update_gru(cf_model* m, int layer, const cf_gru_dir* fw, const cf_gru_dir* bw) {
+    if (!m || !fw || !bw) return fail(CF_ERR_INVALID, "cf_model_update_gru: null argument");
+    int cin = 0;
+    int rc = train_layer_cin(m, layer, &cin);
+    if (rc != CF_OK) return rc;
+    if (fw->cin != cin || bw->cin != cin) return fail(CF_ERR_INVALID, "cf_model_update_gru: input width mismatch");
+    HIP_TRY(hipSetDevice(m->device));
+    const bool last = layer == m->hp.n_layers - 1;
+    const cf_gru_dir* g[2] = {fw, bw};
+    std::vector<float> blob((size_t)2 * gru_pack_floats(cin));
+    std::vector<float> bblob((size_t)2 * gtb_pack_floats(cin));
+    for (int d = 0; d < 2; ++d) {
+        pack_gru_dir(*g[d], cin, cin, last ? m->dense_host + d * CF_H : nullptr, blob.data() + (size_t)d * gru_pack_floats(cin));
+        pack_gru_dir_bwd(*g[d], cin, bblob.data() + (size_t)d * gtb_pack_floats(cin));
+    }
+    HIP_TRY(hipMemcpy(m->d_gru[layer], blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!m->d_gru_bwd[layer]) HIP_TRY(hipMalloc((void**)&m->d_gru_bwd[layer], bblob.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->d_gru_bwd[layer], bblob.data(), bblob.size() * sizeof(float), hipMemcpyHostToDevice));
+    return CF_OK;
+}
+
+extern "C" int cf_gru_train_forward(cf_model* m, int layer, const float* x_frag, float* y_frag, float* stash, int64_t n_windows,
+                                    void* stream) {
+    if (!m || !x_frag || !y_frag || !stash) return fail(CF_ERR_INVALID, "cf_gru_train_forward: null argument");
+    if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_forward: n_windows must be positive");
+    int cin = 0;
+    int rc = train_layer_cin(m, layer, &cin);
+    if (rc != CF_OK) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    const int waves = pick_waves(2 * n_tiles, m->n_cu);
+    const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
+    if (cin == CF_C)
+        hipLaunchKernelGGL((gru_train_fwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(32) * 4, s, m->d_gru[layer],
+                           reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+    else
+        hipLaunchKernelGGL((gru_train_fwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(128) * 4, s, m->d_gru[layer],
+                           reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+extern "C" int cf_gru_train_backward(cf_model* m, int layer, const float* y_frag, const float* stash, const float* dy_frag,
+                                     float* dx_frag, float* da, int64_t n_windows, void* stream) {
+    if (!m || !y_frag || !stash || !dy_frag || !dx_frag || !da) return fail(CF_ERR_INVALID, "cf_gru_train_backward: null argument");
+    if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_backward: n_windows must be positive");
+    int cin = 0;
+    int rc = train_layer_cin(m, layer, &cin);
+    if (rc != CF_OK) return rc;
+    if (!m->d_gru_bwd[layer]) return fail(CF_ERR_INVALID, "cf_gru_train_backward: call cf_model_update_gru for this layer first");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    const int waves = pick_waves(2 * n_tiles, m->n_cu);
+    const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
+    if (cin == CF_C)
+        hipLaunchKernelGGL((gru_train_bwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(32) * 4, s, m->d_gru_bwd[layer],
+                           reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
+                           reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+    else
+        hipLaunchKernelGGL((gru_train_bwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(128) * 4, s, m->d_gru_bwd[layer],
+                           reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
+                           reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
 }
 
 // ---- profiling ---------------------------------------------------------------------------

@@ -1,0 +1,119 @@
+"""Native (HIP) forward + backward of the bidirectional GRU layers for training (BASELINE config 5).
+
+The recurrent part is 95 % of the step's FLOPs and, in eager torch, thousands of tiny kernels.  Here each
+biGRU layer is ONE forward launch (``cf_gru_train_forward``: the inference kernel plus a stash of the
+activated gates) and ONE backward launch (``cf_gru_train_backward``: BPTT over the 35 steps with the
+transposed-role weight fragments), wrapped in a ``torch.autograd.Function``.  The weight gradients are
+``A^T dA`` over all (window, step) pairs -- one library GEMM per matrix (torch.matmul -> rocBLAS); the
+residual blocks, dropout masks, the dense head and the loss stay in torch autograd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+T = 35
+
+
+def nat_to_frag(x):
+    """[N, 35, F] (N multiple of 16, F multiple of 16) -> fragment layout [N/16, 35, F/16, 64, 4]."""
+    n, t, f = x.shape
+    return x.reshape(n // 16, 16, t, f // 16, 4, 4).permute(0, 2, 3, 4, 1, 5).reshape(n // 16, t, f // 16, 64, 4).contiguous()
+
+
+def frag_to_nat(x):
+    """[tiles, 35, M, 64, 4] -> [tiles * 16, 35, 16 M]."""
+    tiles, t, m = x.shape[0], x.shape[1], x.shape[2]
+    return x.reshape(tiles, t, m, 4, 16, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 16, t, m * 16).contiguous()
+
+
+def _gru_dir_struct(wg, bg, wc, bc, keep):
+    arrs = [np.ascontiguousarray(t.detach().to("cpu", dtype=__import__("torch").float32).numpy()) for t in (wg, bg, wc, bc)]
+    keep.extend(arrs)
+    g = N.cf_gru_dir()
+    g.gates_kernel = arrs[0].ctypes.data_as(C.POINTER(C.c_float))
+    g.gates_bias = arrs[1].ctypes.data_as(C.POINTER(C.c_float))
+    g.candidate_kernel = arrs[2].ctypes.data_as(C.POINTER(C.c_float))
+    g.candidate_bias = arrs[3].ctypes.data_as(C.POINTER(C.c_float))
+    g.cin = arrs[2].shape[0] - arrs[2].shape[1]
+    return g
+
+
+def _make_function():
+    import torch
+
+    class NativeBiGRU(torch.autograd.Function):
+        """y = biGRU_layer(x); x [N,35,Cin] -> y [N,35,128] (forward direction features first)."""
+
+        @staticmethod
+        def forward(ctx, x, wg_f, bg_f, wc_f, bc_f, wg_b, bg_b, wc_b, bc_b, engine, layer):
+            lib, handle = engine._lib, engine._handle
+            keep = []
+            fw = _gru_dir_struct(wg_f, bg_f, wc_f, bc_f, keep)
+            bw = _gru_dir_struct(wg_b, bg_b, wc_b, bc_b, keep)
+            N.check(lib.cf_model_update_gru(handle, int(layer), C.byref(fw), C.byref(bw)))
+            n = x.shape[0]
+            npad = (n + 15) // 16 * 16
+            xp = x if npad == n else torch.cat([x, x.new_zeros(npad - n, T, x.shape[2])], 0)
+            x_frag = nat_to_frag(xp.float())
+            tiles = npad // 16
+            y_frag = torch.empty(tiles, T, 8, 64, 4, dtype=torch.float32, device=x.device)
+            stash = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            N.check(lib.cf_gru_train_forward(handle, int(layer), C.c_void_p(x_frag.data_ptr()), C.c_void_p(y_frag.data_ptr()),
+                                             C.c_void_p(stash.data_ptr()), npad, C.c_void_p(stream)))
+            ctx.engine, ctx.layer, ctx.n, ctx.npad = engine, int(layer), n, npad
+            ctx.save_for_backward(xp, y_frag, stash)
+            return frag_to_nat(y_frag)[:n]
+
+        @staticmethod
+        def backward(ctx, dy):
+            xp, y_frag, stash = ctx.saved_tensors
+            engine, layer, n, npad = ctx.engine, ctx.layer, ctx.n, ctx.npad
+            lib, handle = engine._lib, engine._handle
+            dev = xp.device
+            tiles = npad // 16
+            cin = xp.shape[2]
+            dyp = dy if npad == n else torch.cat([dy, dy.new_zeros(npad - n, T, dy.shape[2])], 0)
+            dy_frag = nat_to_frag(dyp.float().contiguous())
+            dx_frag = torch.empty(2, tiles, T, cin // 16, 64, 4, dtype=torch.float32, device=dev)
+            da = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            N.check(lib.cf_gru_train_backward(handle, layer, C.c_void_p(y_frag.data_ptr()), C.c_void_p(stash.data_ptr()),
+                                              C.c_void_p(dy_frag.data_ptr()), C.c_void_p(dx_frag.data_ptr()),
+                                              C.c_void_p(da.data_ptr()), npad, C.c_void_p(stream)))
+            dx = (frag_to_nat(dx_frag[0]) + frag_to_nat(dx_frag[1]))[:n]
+            y = frag_to_nat(y_frag)                                   # [npad, 35, 128]
+            grads = []
+            x2 = xp.reshape(npad * T, cin)
+            for d in range(2):
+                da_d = frag_to_nat(da[:, :, d])                       # [npad, 35, 192]: da_r | da_u | da_c
+                r_d = frag_to_nat(stash[:, :, d, 0:4])                # [npad, 35, 64]
+                h = y[:, :, 64 * d:64 * d + 64]
+                hprev = torch.zeros_like(h)
+                if d == 0:
+                    hprev[:, 1:] = h[:, :-1]                          # forward direction: state before step t is y[t-1]
+                else:
+                    hprev[:, :-1] = h[:, 1:]                          # backward direction: state before step t is y[t+1]
+                da_g = da_d[:, :, :128].reshape(npad * T, 128)
+                da_c = da_d[:, :, 128:].reshape(npad * T, 64)
+                a_g = torch.cat([x2, hprev.reshape(npad * T, 64)], 1)
+                a_c = torch.cat([x2, (r_d * hprev).reshape(npad * T, 64)], 1)
+                grads += [a_g.t() @ da_g, da_g.sum(0), a_c.t() @ da_c, da_c.sum(0)]
+            return (dx.to(dy.dtype),) + tuple(grads) + (None, None)
+
+    return NativeBiGRU
+
+
+_FN = None
+
+
+def native_bigru(x, params8, engine, layer):
+    """Differentiable biGRU layer on the HIP kernels.  params8 = (wg_f, bg_f, wc_f, bc_f, wg_b, bg_b, wc_b, bc_b)."""
+    global _FN
+    if _FN is None:
+        _FN = _make_function()
+    return _FN.apply(x, *params8, engine, layer)

@@ -56,8 +56,11 @@ class TorchResNetRNN(object):
         inv = p[bn(j) + "/gamma"] * torch.rsqrt(p[bn(j) + "/moving_variance"] + 1e-3)
         return y * inv[None, :, None] + (p[bn(j) + "/beta"] - p[bn(j) + "/moving_mean"] * inv)[None, :, None]
 
-    def logits(self, x, keep_prob=1.0, generator=None):
-        """x [N, 35] or [N, 35, 1] -> logits [N, 35]."""
+    def logits(self, x, keep_prob=1.0, generator=None, engine=None):
+        """x [N, 35] or [N, 35, 1] -> logits [N, 35].
+
+        With ``engine`` (a fp32 HipEngine on the same GPU) the biGRU layers run on the native HIP
+        forward/backward kernels (catfish_amd/native_train.py); everything else stays torch autograd."""
         torch = self.torch
         p = self.params
         x = torch.as_tensor(x, dtype=self.dtype, device=self.device)
@@ -74,6 +77,16 @@ class TorchResNetRNN(object):
         a = a.permute(0, 2, 1)                           # [N, T, C]
         n, t_len, _ = a.shape
         for layer in range(self.n_layers):
+            if engine is not None:
+                from .native_train import native_bigru
+                pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell"
+                p8 = [p[(pre % (layer, d)) + k] for d in ("fw", "bw")
+                      for k in ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")]
+                a = native_bigru(a, p8, engine, layer)
+                if keep_prob < 1.0:                      # DropoutWrapper(output_keep_prob): outputs only
+                    mask = torch.floor(keep_prob + torch.rand(a.shape, generator=generator, device=self.device, dtype=self.dtype))
+                    a = a / keep_prob * mask
+                continue
             outs = []
             for dname, rev in (("fw", False), ("bw", True)):
                 pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell" % (layer, dname)
@@ -99,10 +112,10 @@ class TorchResNetRNN(object):
         return (a.reshape(-1, a.shape[2]) @ p["final_fully_connected/kernel"] +
                 p["final_fully_connected/bias"]).reshape(n, t_len)
 
-    def loss(self, x, y, keep_prob=1.0, generator=None):
+    def loss(self, x, y, keep_prob=1.0, generator=None, engine=None):
         """tf.losses.sigmoid_cross_entropy + reduce_mean (rnn_class.py:74-79)."""
         torch = self.torch
-        z = self.logits(x, keep_prob, generator)
+        z = self.logits(x, keep_prob, generator, engine)
         y = torch.as_tensor(y, dtype=self.dtype, device=self.device).reshape(z.shape)
         return torch.nn.functional.binary_cross_entropy_with_logits(z, y, reduction="mean")
 
@@ -163,7 +176,7 @@ class Trainer(object):
     """
 
     def __init__(self, weights, n_layers, n_layers_res, optimizer_choice, learning_rate, keep_prob, device=None,
-                 seed=None, use_graph=None):
+                 seed=None, use_graph=None, native=None):
         import torch
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
@@ -174,7 +187,14 @@ class Trainer(object):
         if seed is not None:
             self.gen.manual_seed(int(seed))
         self.last_loss = None
-        self.use_graph = (self.net.device.type == "cuda") if use_graph is None else bool(use_graph)
+        # native = biGRU layers on the HIP training kernels (default on a GPU for the shipped geometry)
+        self.native = (self.net.device.type == "cuda" and n_layers_res > 0) if native is None else bool(native)
+        self.engine = None
+        if self.native:
+            from .engine import HipEngine
+            self.engine = HipEngine(weights, n_layers=n_layers, n_layers_res=n_layers_res,
+                                    device=self.net.device.index or 0, max_windows_per_pass=256, fuse_layers=False)
+        self.use_graph = (self.net.device.type == "cuda" and not self.native) if use_graph is None else bool(use_graph)
         self._graph = None
         self._static = None
         if seed is not None and self.net.device.type == "cuda":
@@ -213,7 +233,7 @@ class Trainer(object):
             self._graph.replay()
             self.last_loss = float(sloss.detach())
             return self.last_loss
-        loss = self.net.loss(x, y, kp, self.gen)
+        loss = self.net.loss(x, y, kp, self.gen, self.engine)
         loss.backward()
         self.opt.step()
         self.last_loss = float(loss.detach())

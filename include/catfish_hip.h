@@ -145,6 +145,24 @@ int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_samples, int64_t 
 int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets,
                  const int64_t* win_offsets, int64_t n_reads, float* x_out, void* stream);
 
+/* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
+ * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,
+ * on device buffers in the kernels' fragment layout [tile][t][mtile][lane][4] (tile = 16 windows; element
+ * (lane, reg) of M-tile m = feature 16m + 4(lane>>4) + reg of window lane&15):
+ *   x_frag   [tiles][35][cin/16][64][4]      layer input (cin = 32 for layer 0, 128 above)
+ *   y_frag   [tiles][35][8][64][4]           layer output (M-tiles 0-3 forward, 4-7 backward direction)
+ *   stash    [tiles][35][2][12][64][4]       activated r, u gates and candidate c of every step
+ *   dy_frag  like y_frag                     gradient of the loss w.r.t. the layer output
+ *   dx_frag  [2][tiles][35][cin/16][64][4]   gradient w.r.t. the layer input, one slab per direction (add them)
+ *   da       like stash                      pre-activation gradients da_r, da_u (0-7), da_c (8-11); the weight
+ *                                            gradients are dW = A^T dA, formed by the caller with a library GEMM
+ * cf_model_update_gru re-tiles one layer's (updated) weights for both passes. */
+int cf_model_update_gru(cf_model* m, int layer, const cf_gru_dir* fw, const cf_gru_dir* bw);
+int cf_gru_train_forward(cf_model* m, int layer, const float* x_frag, float* y_frag, float* stash,
+                         int64_t n_windows, void* stream);
+int cf_gru_train_backward(cf_model* m, int layer, const float* y_frag, const float* stash, const float* dy_frag,
+                          float* dx_frag, float* da, int64_t n_windows, void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, 1) makes every cf_infer record
  * events around each kernel; cf_profile_read synchronises and returns, for

@@ -25,7 +25,7 @@ def main():
     x = reads[rng.permutation(len(reads))[:256]]
     y = np.repeat((np.arange(256) % 2)[:, None], 35, axis=1).astype(np.float32)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
-    gpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)
+    gpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)     # native HIP biGRU kernels on a GPU
     cpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
     lg = [gpu.train_step(x, y) for _ in range(10)]
     lc = [cpu.train_step(x, y) for _ in range(10)]
@@ -41,7 +41,20 @@ def main():
     if dev == "cuda":
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "training windows/s (config 5, torch autograd + TF-style Adam)", "device": dev,
+    modes = {}
+    if dev == "cuda":
+        for name, kw in (("torch_eager", dict(native=False, use_graph=False)), ("torch_hipgraph", dict(native=False, use_graph=True))):
+            t2 = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=0.8, device=dev, seed=0, **kw)
+            for _ in range(3):
+                t2.train_step(x, y)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                t2.train_step(x, y)
+            torch.cuda.synchronize()
+            modes[name + "_ms_per_step"] = (time.perf_counter() - t1) / 5 * 1e3
+    print(json.dumps({"metric": "training windows/s (config 5: native HIP biGRU fwd/bwd + torch autograd for the rest, TF-style Adam)",
+                      "device": dev, "native": bool(getattr(tr, "native", False)), "other_modes": modes,
                       "value": n * 256 / dt, "ms_per_step": dt / n * 1e3,
                       "loss_10_steps_device": lg, "loss_10_steps_cpu": lc,
                       "max_loss_diff": float(np.max(np.abs(np.array(lg) - np.array(lc))))}))
