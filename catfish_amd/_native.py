@@ -71,10 +71,11 @@ SYMBOLS = {
                                  C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "cf_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "cf_model_update_gru": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(cf_gru_dir), C.POINTER(cf_gru_dir)]),
-    "cf_gru_train_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "cf_gru_train_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_int64, C.c_void_p]),
+    "cf_gru_pack_map": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "cf_gru_train_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p]),
+    "cf_gru_train_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
     "cf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cf_profile_reset": (C.c_int, [C.c_void_p]),
     "cf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -681,8 +681,6 @@ struct cf_model {
     std::vector<float*> d_res;   // per residual block packed weights
     std::vector<float*> d_gru;   // per layer packed weights [2 dirs]
     std::vector<int> gru_cin;
-    std::vector<float*> d_gru_bwd;  // per layer packed backward weights [2 dirs] (training, created on first update)
-    float dense_host[2 * CF_H] = {0};
     std::vector<char*> d_res_b;  // per residual block packed bf16 weights (precision != fp32)
     std::vector<char*> d_gru_b;  // per layer packed bf16 weights [2 dirs] (precision != fp32)
     int np = 0;                  // bf16 parts per operand: 0 = fp32 path, 1 = bf16, 2 = bf16x3
@@ -853,7 +851,6 @@ extern "C" void cf_model_destroy(cf_model* m) {
     for (float* p : m->d_res) if (p) (void)hipFree(p);
     for (float* p : m->d_gru) if (p) (void)hipFree(p);
     for (char* p : m->d_gru_b) if (p) (void)hipFree(p);
-    for (float* p : m->d_gru_bwd) if (p) (void)hipFree(p);
     for (char* p : m->d_res_b) if (p) (void)hipFree(p);
     for (auto& sl : m->slots) {
         for (int i = 0; i < 2; ++i) { if (sl.d_a[i]) (void)hipFree(sl.d_a[i]); if (sl.d_y[i]) (void)hipFree(sl.d_y[i]); }
@@ -939,8 +936,6 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         }
     }
     m->dense_bias = w->dense_bias[0];
-    memcpy(m->dense_host, w->dense_kernel, sizeof(m->dense_host));
-    m->d_gru_bwd.assign(hp->n_layers, nullptr);
     // workspace
     if (rc == CF_OK) {
         int64_t cap = hp->max_windows_per_pass > 0 ? hp->max_windows_per_pass : 32768;
@@ -1304,40 +1299,51 @@ extern "C" int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_
 }
 
 // ---- training support (BASELINE config 5) ------------------------------------------------
-static int train_layer_cin(const cf_model* m, int layer, int* cin) {
-    if (layer < 0 || layer >= m->hp.n_layers) return fail(CF_ERR_INVALID, "training: layer out of range");
-    if (m->np != 0 || m->hp.n_layers_res == 0) return fail(CF_ERR_INVALID, "training kernels need CF_PREC_FP32 and the ResNetRNN type");
-    *cin = layer == 0 ? CF_C : 2 * CF_H;
-    return CF_OK;
-}
-
-extern "C" int cf_model_update_gru(cf_model* m, int layer, const cf_gru_dir* fw, const cf_gru_dir* bw) {
-    if (!m || !fw || !bw) return fail(CF_ERR_INVALID, "cf_model_update_gru: null argument");
-    int cin = 0;
-    int rc = train_layer_cin(m, layer, &cin);
-    if (rc != CF_OK) return rc;
-    if (fw->cin != cin || bw->cin != cin) return fail(CF_ERR_INVALID, "cf_model_update_gru: input width mismatch");
-    HIP_TRY(hipSetDevice(m->device));
-    const bool last = layer == m->hp.n_layers - 1;
-    const cf_gru_dir* g[2] = {fw, bw};
-    std::vector<float> blob((size_t)2 * gru_pack_floats(cin));
-    std::vector<float> bblob((size_t)2 * gtb_pack_floats(cin));
-    for (int d = 0; d < 2; ++d) {
-        pack_gru_dir(*g[d], cin, cin, last ? m->dense_host + d * CF_H : nullptr, blob.data() + (size_t)d * gru_pack_floats(cin));
-        pack_gru_dir_bwd(*g[d], cin, bblob.data() + (size_t)d * gtb_pack_floats(cin));
+// Gather map of the weight re-tiling, so that a trainer can re-tile updated weights ON DEVICE
+// (packed = src[idx] * scale) instead of round-tripping through the host packers every step.
+// src (one direction) = [gates_kernel ((cin+64)*128) | candidate_kernel ((cin+64)*64) | gates_bias (128) |
+// candidate_bias (64) | 0.0]; the map is derived from the host packers themselves (index-encoded weights).
+extern "C" int cf_gru_pack_map(int32_t cin, int32_t backward, int32_t* idx, float* scale, int64_t capacity, int64_t* n_floats) {
+    if (cin != CF_C && cin != 2 * CF_H) return fail(CF_ERR_INVALID, "cf_gru_pack_map: cin must be 32 or 128");
+    const int64_t n = backward ? gtb_pack_floats(cin) : gru_pack_floats(cin);
+    if (n_floats) *n_floats = n;
+    if (!idx || !scale) return CF_OK;                       // size query
+    if (capacity < n) return fail(CF_ERR_INVALID, "cf_gru_pack_map: buffers too small");
+    const int rows = cin + CF_H;
+    const size_t n_gk = (size_t)rows * 2 * CF_H, n_ck = (size_t)rows * CF_H;
+    const size_t n_src = n_gk + n_ck + 2 * CF_H + CF_H;     // + the trailing zero slot = index n_src
+    std::vector<float> gk(n_gk), ck(n_ck), gb(2 * CF_H), cb(CF_H);
+    cf_gru_dir g;
+    g.gates_kernel = gk.data(); g.gates_bias = gb.data(); g.candidate_kernel = ck.data(); g.candidate_bias = cb.data(); g.cin = cin;
+    std::vector<float> ones((size_t)n), enc((size_t)n);
+    auto run = [&](std::vector<float>& out) {
+        if (backward) pack_gru_dir_bwd(g, cin, out.data());
+        else pack_gru_dir(g, cin, cin, nullptr, out.data());
+    };
+    for (auto* v : {&gk, &ck, &gb, &cb}) std::fill(v->begin(), v->end(), 1.0f);
+    run(ones);                                              // = the scale applied to every packed element (0 = constant zero)
+    size_t base = 0;
+    for (auto* v : {&gk, &ck, &gb, &cb}) { for (size_t i = 0; i < v->size(); ++i) (*v)[i] = (float)(base + i + 1); base += v->size(); }
+    run(enc);
+    for (int64_t i = 0; i < n; ++i) {
+        scale[i] = ones[i];
+        idx[i] = ones[i] == 0.f ? (int32_t)n_src : (int32_t)(std::llround((double)enc[i] / (double)ones[i]) - 1);
+        if (idx[i] < 0 || idx[i] > (int32_t)n_src) return fail(CF_ERR_INVALID, "cf_gru_pack_map: internal index error");
     }
-    HIP_TRY(hipMemcpy(m->d_gru[layer], blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (!m->d_gru_bwd[layer]) HIP_TRY(hipMalloc((void**)&m->d_gru_bwd[layer], bblob.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(m->d_gru_bwd[layer], bblob.data(), bblob.size() * sizeof(float), hipMemcpyHostToDevice));
     return CF_OK;
 }
 
-extern "C" int cf_gru_train_forward(cf_model* m, int layer, const float* x_frag, float* y_frag, float* stash, int64_t n_windows,
-                                    void* stream) {
-    if (!m || !x_frag || !y_frag || !stash) return fail(CF_ERR_INVALID, "cf_gru_train_forward: null argument");
+static int train_cin_ok(const cf_model* m, int cin) {
+    if (m->np != 0) return fail(CF_ERR_INVALID, "training kernels need a CF_PREC_FP32 model");
+    if (cin != CF_C && cin != 2 * CF_H) return fail(CF_ERR_INVALID, "training kernels: cin must be 32 or 128");
+    return CF_OK;
+}
+
+extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag, float* stash,
+                                    int64_t n_windows, void* stream) {
+    if (!m || !wpack || !x_frag || !y_frag || !stash) return fail(CF_ERR_INVALID, "cf_gru_train_forward: null argument");
     if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_forward: n_windows must be positive");
-    int cin = 0;
-    int rc = train_layer_cin(m, layer, &cin);
+    int rc = train_cin_ok(m, cin);
     if (rc != CF_OK) return rc;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1345,34 +1351,33 @@ extern "C" int cf_gru_train_forward(cf_model* m, int layer, const float* x_frag,
     const int waves = pick_waves(2 * n_tiles, m->n_cu);
     const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
     if (cin == CF_C)
-        hipLaunchKernelGGL((gru_train_fwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(32) * 4, s, m->d_gru[layer],
+        hipLaunchKernelGGL((gru_train_fwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(32) * 4, s, wpack,
                            reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
     else
-        hipLaunchKernelGGL((gru_train_fwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(128) * 4, s, m->d_gru[layer],
+        hipLaunchKernelGGL((gru_train_fwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(128) * 4, s, wpack,
                            reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }
 
-extern "C" int cf_gru_train_backward(cf_model* m, int layer, const float* y_frag, const float* stash, const float* dy_frag,
-                                     float* dx_frag, float* da, int64_t n_windows, void* stream) {
-    if (!m || !y_frag || !stash || !dy_frag || !dx_frag || !da) return fail(CF_ERR_INVALID, "cf_gru_train_backward: null argument");
+extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
+                                     const float* dy_frag, float* dx_frag, float* da, int64_t n_windows, void* stream) {
+    if (!m || !wpack_bwd || !y_frag || !stash || !dy_frag || !dx_frag || !da)
+        return fail(CF_ERR_INVALID, "cf_gru_train_backward: null argument");
     if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_backward: n_windows must be positive");
-    int cin = 0;
-    int rc = train_layer_cin(m, layer, &cin);
+    int rc = train_cin_ok(m, cin);
     if (rc != CF_OK) return rc;
-    if (!m->d_gru_bwd[layer]) return fail(CF_ERR_INVALID, "cf_gru_train_backward: call cf_model_update_gru for this layer first");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
     const int waves = pick_waves(2 * n_tiles, m->n_cu);
     const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
     if (cin == CF_C)
-        hipLaunchKernelGGL((gru_train_bwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(32) * 4, s, m->d_gru_bwd[layer],
+        hipLaunchKernelGGL((gru_train_bwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(32) * 4, s, wpack_bwd,
                            reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                            reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
     else
-        hipLaunchKernelGGL((gru_train_bwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(128) * 4, s, m->d_gru_bwd[layer],
+        hipLaunchKernelGGL((gru_train_bwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(128) * 4, s, wpack_bwd,
                            reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                            reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
     HIP_TRY(hipGetLastError());

@@ -3,7 +3,8 @@
 The recurrent part is 95 % of the step's FLOPs and, in eager torch, thousands of tiny kernels.  Here each
 biGRU layer is ONE forward launch (``cf_gru_train_forward``: the inference kernel plus a stash of the
 activated gates) and ONE backward launch (``cf_gru_train_backward``: BPTT over the 35 steps with the
-transposed-role weight fragments), wrapped in a ``torch.autograd.Function``.  The weight gradients are
+transposed-role weight fragments), wrapped in a ``torch.autograd.Function``.  The updated weights are
+re-tiled on the device every step through the gather map of ``cf_gru_pack_map`` (no host round trip).  The weight gradients are
 ``A^T dA`` over all (window, step) pairs -- one library GEMM per matrix (torch.matmul -> rocBLAS); the
 residual blocks, dropout masks, the dense head and the loss stay in torch autograd.
 """
@@ -30,16 +31,34 @@ def frag_to_nat(x):
     return x.reshape(tiles, t, m, 4, 16, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 16, t, m * 16).contiguous()
 
 
-def _gru_dir_struct(wg, bg, wc, bc, keep):
-    arrs = [np.ascontiguousarray(t.detach().to("cpu", dtype=__import__("torch").float32).numpy()) for t in (wg, bg, wc, bc)]
-    keep.extend(arrs)
-    g = N.cf_gru_dir()
-    g.gates_kernel = arrs[0].ctypes.data_as(C.POINTER(C.c_float))
-    g.gates_bias = arrs[1].ctypes.data_as(C.POINTER(C.c_float))
-    g.candidate_kernel = arrs[2].ctypes.data_as(C.POINTER(C.c_float))
-    g.candidate_bias = arrs[3].ctypes.data_as(C.POINTER(C.c_float))
-    g.cin = arrs[2].shape[0] - arrs[2].shape[1]
-    return g
+_MAPS = {}
+
+
+def pack_maps(cin, device):
+    """(idx_fwd, scale_fwd, idx_bwd, scale_bwd) device tensors of cf_gru_pack_map, cached per (cin, device)."""
+    import torch
+    key = (int(cin), str(device))
+    if key not in _MAPS:
+        lib = N.lib()
+        out = []
+        for backward in (0, 1):
+            n = C.c_int64()
+            N.check(lib.cf_gru_pack_map(int(cin), backward, None, None, 0, C.byref(n)))
+            idx = np.empty(n.value, dtype=np.int32)
+            scale = np.empty(n.value, dtype=np.float32)
+            N.check(lib.cf_gru_pack_map(int(cin), backward, idx.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p),
+                                        n.value, C.byref(n)))
+            out += [torch.from_numpy(idx.astype(np.int64)).to(device), torch.from_numpy(scale).to(device)]
+        _MAPS[key] = tuple(out)
+    return _MAPS[key]
+
+
+def retile(params4, idx, scale):
+    """One direction's (gates_kernel, gates_bias, candidate_kernel, candidate_bias) -> packed blob, on device."""
+    import torch
+    wg, bg, wc, bc = params4
+    src = torch.cat([wg.reshape(-1), wc.reshape(-1), bg.reshape(-1), bc.reshape(-1), wg.new_zeros(1)]).float()
+    return src[idx] * scale
 
 
 def _make_function():
@@ -49,30 +68,32 @@ def _make_function():
         """y = biGRU_layer(x); x [N,35,Cin] -> y [N,35,128] (forward direction features first)."""
 
         @staticmethod
-        def forward(ctx, x, wg_f, bg_f, wc_f, bc_f, wg_b, bg_b, wc_b, bc_b, engine, layer):
+        def forward(ctx, x, wg_f, bg_f, wc_f, bc_f, wg_b, bg_b, wc_b, bc_b, engine):
             lib, handle = engine._lib, engine._handle
-            keep = []
-            fw = _gru_dir_struct(wg_f, bg_f, wc_f, bc_f, keep)
-            bw = _gru_dir_struct(wg_b, bg_b, wc_b, bc_b, keep)
-            N.check(lib.cf_model_update_gru(handle, int(layer), C.byref(fw), C.byref(bw)))
+            cin = int(x.shape[2])
+            idx_f, sc_f, idx_b, sc_b = pack_maps(cin, x.device)
+            with torch.no_grad():
+                dirs = ((wg_f, bg_f, wc_f, bc_f), (wg_b, bg_b, wc_b, bc_b))
+                wpack = torch.stack([retile(d, idx_f, sc_f) for d in dirs]).contiguous()       # [2, n_floats] on device
+                wpack_bwd = torch.stack([retile(d, idx_b, sc_b) for d in dirs]).contiguous()
             n = x.shape[0]
             npad = (n + 15) // 16 * 16
-            xp = x if npad == n else torch.cat([x, x.new_zeros(npad - n, T, x.shape[2])], 0)
+            xp = x if npad == n else torch.cat([x, x.new_zeros(npad - n, T, cin)], 0)
             x_frag = nat_to_frag(xp.float())
             tiles = npad // 16
             y_frag = torch.empty(tiles, T, 8, 64, 4, dtype=torch.float32, device=x.device)
             stash = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            N.check(lib.cf_gru_train_forward(handle, int(layer), C.c_void_p(x_frag.data_ptr()), C.c_void_p(y_frag.data_ptr()),
-                                             C.c_void_p(stash.data_ptr()), npad, C.c_void_p(stream)))
-            ctx.engine, ctx.layer, ctx.n, ctx.npad = engine, int(layer), n, npad
-            ctx.save_for_backward(xp, y_frag, stash)
+            N.check(lib.cf_gru_train_forward(handle, cin, C.c_void_p(wpack.data_ptr()), C.c_void_p(x_frag.data_ptr()),
+                                             C.c_void_p(y_frag.data_ptr()), C.c_void_p(stash.data_ptr()), npad, C.c_void_p(stream)))
+            ctx.engine, ctx.n, ctx.npad = engine, n, npad
+            ctx.save_for_backward(xp, y_frag, stash, wpack_bwd)
             return frag_to_nat(y_frag)[:n]
 
         @staticmethod
         def backward(ctx, dy):
-            xp, y_frag, stash = ctx.saved_tensors
-            engine, layer, n, npad = ctx.engine, ctx.layer, ctx.n, ctx.npad
+            xp, y_frag, stash, wpack_bwd = ctx.saved_tensors
+            engine, n, npad = ctx.engine, ctx.n, ctx.npad
             lib, handle = engine._lib, engine._handle
             dev = xp.device
             tiles = npad // 16
@@ -82,9 +103,9 @@ def _make_function():
             dx_frag = torch.empty(2, tiles, T, cin // 16, 64, 4, dtype=torch.float32, device=dev)
             da = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            N.check(lib.cf_gru_train_backward(handle, layer, C.c_void_p(y_frag.data_ptr()), C.c_void_p(stash.data_ptr()),
-                                              C.c_void_p(dy_frag.data_ptr()), C.c_void_p(dx_frag.data_ptr()),
-                                              C.c_void_p(da.data_ptr()), npad, C.c_void_p(stream)))
+            N.check(lib.cf_gru_train_backward(handle, int(cin), C.c_void_p(wpack_bwd.data_ptr()), C.c_void_p(y_frag.data_ptr()),
+                                              C.c_void_p(stash.data_ptr()), C.c_void_p(dy_frag.data_ptr()),
+                                              C.c_void_p(dx_frag.data_ptr()), C.c_void_p(da.data_ptr()), npad, C.c_void_p(stream)))
             dx = (frag_to_nat(dx_frag[0]) + frag_to_nat(dx_frag[1]))[:n]
             y = frag_to_nat(y_frag)                                   # [npad, 35, 128]
             grads = []
@@ -103,7 +124,7 @@ def _make_function():
                 a_g = torch.cat([x2, hprev.reshape(npad * T, 64)], 1)
                 a_c = torch.cat([x2, (r_d * hprev).reshape(npad * T, 64)], 1)
                 grads += [a_g.t() @ da_g, da_g.sum(0), a_c.t() @ da_c, da_c.sum(0)]
-            return (dx.to(dy.dtype),) + tuple(grads) + (None, None)
+            return (dx.to(dy.dtype),) + tuple(grads) + (None,)
 
     return NativeBiGRU
 
@@ -111,9 +132,9 @@ def _make_function():
 _FN = None
 
 
-def native_bigru(x, params8, engine, layer):
+def native_bigru(x, params8, engine):
     """Differentiable biGRU layer on the HIP kernels.  params8 = (wg_f, bg_f, wc_f, bc_f, wg_b, bg_b, wc_b, bc_b)."""
     global _FN
     if _FN is None:
         _FN = _make_function()
-    return _FN.apply(x, *params8, engine, layer)
+    return _FN.apply(x, *params8, engine)

@@ -82,7 +82,7 @@ class TorchResNetRNN(object):
                 pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell"
                 p8 = [p[(pre % (layer, d)) + k] for d in ("fw", "bw")
                       for k in ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")]
-                a = native_bigru(a, p8, engine, layer)
+                a = native_bigru(a, p8, engine)
                 if keep_prob < 1.0:                      # DropoutWrapper(output_keep_prob): outputs only
                     mask = torch.floor(keep_prob + torch.rand(a.shape, generator=generator, device=self.device, dtype=self.dtype))
                     a = a / keep_prob * mask
@@ -145,25 +145,40 @@ class TFOptimizer(object):
             self.mom = {k: torch.zeros_like(v) for k, v in params.items()}
 
     def step(self):
+        """One update of every parameter with multi-tensor (``torch._foreach_*``) ops: a handful of launches
+        instead of ~8 per parameter tensor (66 tensors)."""
         torch = self.torch
         with torch.no_grad():
+            keys = [k for k, p in self.params.items() if p.grad is not None]
+            ps = [self.params[k] for k in keys]
+            gs = [self.params[k].grad for k in keys]
             self.t.add_(1.0)
-            b1, b2, eps = 0.9, 0.999, 1e-8
             if self.choice == "Adam":
-                lr_t = self.lr * torch.sqrt(1.0 - torch.pow(self._b2, self.t)) / (1.0 - torch.pow(self._b1, self.t))
-            for k, p in self.params.items():
-                g = p.grad
-                if g is None:
-                    continue
-                if self.choice == "Adam":
-                    self.m[k].mul_(b1).add_(g, alpha=1 - b1)
-                    self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
-                    p.sub_(lr_t.to(p.dtype) * self.m[k] / (self.v[k].sqrt() + eps))
-                else:
-                    decay, eps = 0.9, 1e-10
-                    self.ms[k].mul_(decay).addcmul_(g, g, value=1 - decay)
-                    p.sub_(self.lr * g / torch.sqrt(self.ms[k] + eps))         # momentum = 0
-                if not self.keep_grads:
+                b1, b2, eps = 0.9, 0.999, 1e-8
+                lr_t = (self.lr * torch.sqrt(1.0 - torch.pow(self._b2, self.t)) / (1.0 - torch.pow(self._b1, self.t))).to(ps[0].dtype)
+                ms = [self.m[k] for k in keys]
+                vs = [self.v[k] for k in keys]
+                torch._foreach_mul_(ms, b1)
+                torch._foreach_add_(ms, gs, alpha=1 - b1)
+                torch._foreach_mul_(vs, b2)
+                torch._foreach_addcmul_(vs, gs, gs, value=1 - b2)
+                den = torch._foreach_sqrt(vs)
+                torch._foreach_add_(den, eps)
+                upd = torch._foreach_div(ms, den)
+                torch._foreach_mul_(upd, lr_t)                     # lr_t is a device scalar tensor: no host sync
+                torch._foreach_sub_(ps, upd)
+            else:
+                decay, eps = 0.9, 1e-10
+                rms = [self.ms[k] for k in keys]
+                torch._foreach_mul_(rms, decay)
+                torch._foreach_addcmul_(rms, gs, gs, value=1 - decay)
+                den = torch._foreach_add(rms, eps)
+                torch._foreach_sqrt_(den)
+                upd = torch._foreach_div(gs, den)                  # momentum = 0
+                torch._foreach_mul_(upd, self.lr)
+                torch._foreach_sub_(ps, upd)
+            if not self.keep_grads:
+                for p in ps:
                     p.grad = None
 
 
@@ -194,7 +209,7 @@ class Trainer(object):
             from .engine import HipEngine
             self.engine = HipEngine(weights, n_layers=n_layers, n_layers_res=n_layers_res,
                                     device=self.net.device.index or 0, max_windows_per_pass=256, fuse_layers=False)
-        self.use_graph = (self.net.device.type == "cuda" and not self.native) if use_graph is None else bool(use_graph)
+        self.use_graph = (self.net.device.type == "cuda") if use_graph is None else bool(use_graph)
         self._graph = None
         self._static = None
         if seed is not None and self.net.device.type == "cuda":
@@ -209,14 +224,14 @@ class Trainer(object):
         side.wait_stream(torch.cuda.current_stream(self.net.device))
         with torch.cuda.stream(side):                       # warm-up off the capture stream (allocator, lazy init)
             for _ in range(2):
-                loss = self.net.loss(sx, sy, self.keep_prob, None)
+                loss = self.net.loss(sx, sy, self.keep_prob, None, self.engine)
                 loss.backward()
                 for p in self.net.trainable().values():
                     p.grad = None
         torch.cuda.current_stream(self.net.device).wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            sloss = self.net.loss(sx, sy, self.keep_prob, None)
+            sloss = self.net.loss(sx, sy, self.keep_prob, None, self.engine)
             sloss.backward()
             self.opt.step()
         self._graph, self._static = g, (sx, sy, sloss)

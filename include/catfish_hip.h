@@ -156,12 +156,16 @@ int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets,
  *   dx_frag  [2][tiles][35][cin/16][64][4]   gradient w.r.t. the layer input, one slab per direction (add them)
  *   da       like stash                      pre-activation gradients da_r, da_u (0-7), da_c (8-11); the weight
  *                                            gradients are dW = A^T dA, formed by the caller with a library GEMM
- * cf_model_update_gru re-tiles one layer's (updated) weights for both passes. */
-int cf_model_update_gru(cf_model* m, int layer, const cf_gru_dir* fw, const cf_gru_dir* bw);
-int cf_gru_train_forward(cf_model* m, int layer, const float* x_frag, float* y_frag, float* stash,
-                         int64_t n_windows, void* stream);
-int cf_gru_train_backward(cf_model* m, int layer, const float* y_frag, const float* stash, const float* dy_frag,
-                          float* dx_frag, float* da, int64_t n_windows, void* stream);
+ * wpack / wpack_bwd: device pointers to the re-tiled weights of BOTH directions ([2][n_floats]), owned by the
+ * caller.  cf_gru_pack_map returns the gather map of that re-tiling for one direction, so a trainer can
+ * rebuild them on device after every optimizer step: packed[i] = src[idx[i]] * scale[i] with
+ * src = [gates_kernel | candidate_kernel | gates_bias | candidate_bias | 0.0] (TF layout, flattened).
+ * Call it with idx = scale = NULL to query n_floats. */
+int cf_gru_pack_map(int32_t cin, int32_t backward, int32_t* idx, float* scale, int64_t capacity, int64_t* n_floats);
+int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag,
+                         float* stash, int64_t n_windows, void* stream);
+int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
+                          const float* dy_frag, float* dx_frag, float* da, int64_t n_windows, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, 1) makes every cf_infer record

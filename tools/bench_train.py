@@ -43,7 +43,8 @@ def main():
     dt = time.perf_counter() - t0
     modes = {}
     if dev == "cuda":
-        for name, kw in (("torch_eager", dict(native=False, use_graph=False)), ("torch_hipgraph", dict(native=False, use_graph=True))):
+        for name, kw in (("torch_eager", dict(native=False, use_graph=False)), ("torch_hipgraph", dict(native=False, use_graph=True)),
+                         ("native_eager", dict(native=True, use_graph=False))):
             t2 = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=0.8, device=dev, seed=0, **kw)
             for _ in range(3):
                 t2.train_step(x, y)
