@@ -354,13 +354,16 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                 for (int m = 0; m < 4; ++m) if (!(CF_ABLATE & 2) || s == CF_T - 1) dst[m * 64] = h[m];
             } else {
                 // partial logit of this direction: sum_f w[f] * h[f]   (final_fully_connected/MatMul)
-                float p = 0.f;
+                // summation order shared with the cooperative kernel (bit-identical results): one fma chain per
+                // M-tile, the four M-tile sums added in order, then the lane quarters
+                float pm[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const f32x4 wd = D4[m * 4];
-                    p = fmaf(wd.x, h[m].x, p); p = fmaf(wd.y, h[m].y, p);
-                    p = fmaf(wd.z, h[m].z, p); p = fmaf(wd.w, h[m].w, p);
+                    pm[m] = wd.x * h[m].x;
+                    pm[m] = fmaf(wd.y, h[m].y, pm[m]); pm[m] = fmaf(wd.z, h[m].z, pm[m]); pm[m] = fmaf(wd.w, h[m].w, pm[m]);
                 }
+                float p = ((pm[0] + pm[1]) + pm[2]) + pm[3];
                 p += __shfl_xor(p, 16);
                 p += __shfl_xor(p, 32);
                 if (lane < 16) P[(((int64_t)dir * n_tiles + tile) * CF_T + t) * 16 + lane] = p;
@@ -479,6 +482,8 @@ __global__ __launch_bounds__(512, 2) void gru_fused_kernel(cf_fused_args a) {
     }
 }
 
+#define CF_COOP_XCH_FLOATS (2 * 4 * 64 * 4 + 4 * 64)   // LDS exchange area of the cooperative kernel: h, r*h, dense partials
+#include "gru_coop.hpp"
 #include "gru_train.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -976,6 +981,12 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_layer_kernel<128, false>, gru_pack_floats(128) * 4);
         optin((const void*)gru_layer_kernel<128, true>, gru_pack_floats(128) * 4);
         optin((const void*)gru_fused_kernel, gru_pack_floats(128) * 4 + 16);
+        optin((const void*)gru_layer_coop_kernel<16, false>, (gru_pack_floats(16) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_layer_coop_kernel<16, true>, (gru_pack_floats(16) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_layer_coop_kernel<32, false>, (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_layer_coop_kernel<32, true>, (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_layer_coop_kernel<128, false>, (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_layer_coop_kernel<128, true>, (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4);
         optin((const void*)gru_train_fwd_kernel<32>, gru_pack_floats(32) * 4);
         optin((const void*)gru_train_fwd_kernel<128>, gru_pack_floats(128) * 4);
         optin((const void*)gru_train_bwd_kernel<32>, gtb_pack_floats(32) * 4);
@@ -1025,6 +1036,18 @@ static int pick_waves(int n_tile_tasks, int n_cu) {
 
 template <int CIN, bool LAST>
 static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
+    static const int coop_env = getenv("CATFISH_COOP") ? atoi(getenv("CATFISH_COOP")) : -1;      // A/B knob for tools/
+    const bool coop = coop_env >= 0 ? coop_env != 0 : 2 * n_tiles <= m->n_cu;                     // latency mode: every tile gets a CU
+    if (coop && !(CF_ABLATE & 4)) {
+        size_t pi = 0;
+        int rc = prof_begin(m, slot, s, &pi);
+        if (rc != CF_OK) return rc;
+        const int gx = std::min(n_tiles, std::max(1, m->n_cu / 2));
+        hipLaunchKernelGGL((gru_layer_coop_kernel<CIN, LAST>), dim3(gx, 2), dim3(256), (gru_pack_floats(CIN) + CF_COOP_XCH_FLOATS) * 4, s,
+                           wpack, reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles);
+        HIP_TRY(hipGetLastError());
+        return prof_end(m, s, pi);
+    }
     const int waves = (CF_ABLATE & 4) ? 4 : pick_waves(2 * n_tiles, m->n_cu);
     const int groups = (n_tiles + waves - 1) / waves;             // one workgroup pass = one tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;            // persistent: half the CUs per direction

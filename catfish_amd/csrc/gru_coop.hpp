@@ -1,0 +1,144 @@
+// gru_coop.hpp -- latency mode of the fp32 biGRU layer: FOUR waves (one per SIMD) cooperate on ONE tile of 16
+// windows.  Included by catfish_hip.hip.
+//
+// A single read is 8 tiles x 2 directions; in the throughput kernel a tile is one wave and the 35-step chain
+// costs 576 MFMAs x 32 cycles per step.  Here wave w owns output M-tiles {r[w], u[w], c[w]} (16 hidden units),
+// i.e. 144 MFMAs per step, and the waves exchange r*h and h' through 8 KiB of LDS with two s_barriers per step.
+// Same packed weights, same arithmetic per element (the k order of every accumulation is unchanged), so the
+// results are bit-identical to gru_layer_kernel.
+#pragma once
+
+template <int W>
+__device__ __forceinline__ float pick4(const f32x4& a) { return a[W]; }
+
+template <int CIN, bool LAST, int W>
+__device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ X,
+                                              f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles) {
+    constexpr int KGX = CIN / 16;
+    constexpr int KSX = CIN / 4;
+    constexpr int XN4 = gru_x_floats(CIN) / 4;
+    constexpr int HG4 = gru_hg_floats() / 4;
+    constexpr int BIAS = gru_bias_off(CIN);
+    constexpr int DENSE = gru_dense_off(CIN);
+    const int q = lane >> 4;
+    const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;
+    const f32x4* WG = WX + XN4;
+    const f32x4* WC = WG + HG4;
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;
+    f32x4* hx = reinterpret_cast<f32x4*>(xch) + lane;              // [4 M-tiles][64 lanes] f32x4: the state h
+    f32x4* rx = hx + 4 * 64;                                        // r * h
+    float* pl = xch + 2 * 4 * 64 * 4;                               // [4 waves][64 lanes] dense partial sums (LAST)
+
+    hx[W * 64] = (f32x4){0, 0, 0, 0};                               // GRUCellZeroState (every wave zeroes its own tile)
+    __syncthreads();
+    f32x4 hown = {0, 0, 0, 0};
+    f32x4 xc[KGX];
+    {
+        const int t0 = dir ? (CF_T - 1) : 0;
+        const f32x4* src = X + ((int64_t)tile * CF_T + t0) * KGX * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+    }
+    for (int s = 0; s < CF_T; ++s) {
+        const int t = dir ? (CF_T - 1 - s) : s;
+        f32x4 hf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hf[m] = hx[m * 64];
+        f32x4 ar = B4[(0 + W) * 4], au = B4[(4 + W) * 4], acnd = B4[(8 + W) * 4];
+        f32x4 c0 = WX[0], c1 = WX[64], c2 = WX[128], n0, n1, n2;
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+            if (ks + 1 < KSX) { n0 = WX[((ks + 1) * 3 + 0) * 64]; n1 = WX[((ks + 1) * 3 + 1) * 64]; n2 = WX[((ks + 1) * 3 + 2) * 64]; }
+            else { n0 = WG[0]; n1 = WG[64]; }
+            const float b = xc[ks >> 2][ks & 3];
+            ar = MFMA16(pick4<W>(c0), b, ar);
+            au = MFMA16(pick4<W>(c1), b, au);
+            acnd = MFMA16(pick4<W>(c2), b, acnd);
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = n0; c1 = n1; c2 = n2;
+        }
+        {
+            int tn = dir ? (t - 1) : (t + 1);
+            tn = tn < 0 ? 0 : (tn > CF_T - 1 ? CF_T - 1 : tn);
+            const f32x4* src = X + ((int64_t)tile * CF_T + tn) * KGX * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 1 < 16) { n0 = WG[((ks + 1) * 2 + 0) * 64]; n1 = WG[((ks + 1) * 2 + 1) * 64]; }
+            else { n0 = WC[0]; }
+            const float b = hf[ks >> 2][ks & 3];
+            ar = MFMA16(pick4<W>(c0), b, ar);
+            au = MFMA16(pick4<W>(c1), b, au);
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = n0; c1 = n1;
+        }
+        f32x4 rh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rh[r] = cf_sigmoid_pre(ar[r]) * hown[r];
+        rx[W * 64] = rh;
+        __syncthreads();
+        f32x4 rf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) rf[m] = rx[m * 64];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 1 < 16) n0 = WC[(ks + 1) * 64];
+            const float b = rf[ks >> 2][ks & 3];
+            acnd = MFMA16(pick4<W>(c0), b, acnd);
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = n0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u = cf_sigmoid_pre(au[r]);
+            const float c = cf_tanh_pre(acnd[r]);
+            hown[r] = fmaf(u, hown[r] - c, c);
+        }
+        hx[W * 64] = hown;
+        if constexpr (!LAST) {
+            Y[(((int64_t)tile * CF_T + t) * 8 + dir * 4 + W) * 64 + lane] = hown;
+        } else {
+            const f32x4 wd = *(reinterpret_cast<const f32x4*>(lds + DENSE) + q + W * 4);
+            float p = wd.x * hown.x;
+            p = fmaf(wd.y, hown.y, p); p = fmaf(wd.z, hown.z, p); p = fmaf(wd.w, hown.w, p);
+            pl[W * 64 + lane] = p;                                  // this M-tile's chain, per lane
+        }
+        __syncthreads();
+        if constexpr (LAST && W == 0) {
+            // the one-wave kernel's order: M-tile sums added in order, then the lane quarters
+            float p = ((pl[lane] + pl[64 + lane]) + pl[128 + lane]) + pl[192 + lane];
+            p += __shfl_xor(p, 16);
+            p += __shfl_xor(p, 32);
+            if (lane < 16) P[(((int64_t)dir * n_tiles + tile) * CF_T + t) * 16 + lane] = p;
+        }
+    }
+}
+
+template <int CIN, bool LAST>
+__global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
+                                                                f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK = gru_pack_floats(CIN);
+    const int dir = blockIdx.y;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 8
+        for (int i = threadIdx.x; i < PACK / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xch = lds + PACK;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        switch (wave) {
+            case 0: gru_tile_coop<CIN, LAST, 0>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+            case 1: gru_tile_coop<CIN, LAST, 1>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+            case 2: gru_tile_coop<CIN, LAST, 2>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+            default: gru_tile_coop<CIN, LAST, 3>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+        }
+        __syncthreads();
+    }
+}
