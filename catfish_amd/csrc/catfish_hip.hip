@@ -45,6 +45,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CF_ABLATE
 #define CF_ABLATE 0
 #endif
+#ifndef CF_PREFETCH
+#define CF_PREFETCH 1        // k-steps of A-fragment prefetch in the fp32 GRU step (1 or 2)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -256,17 +259,21 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             for (int mo = 0; mo < 12; ++mo) acc[mo] = B4[mo * 4];
             // The A fragments are software-pipelined one k-step ahead by hand; the
             // sched_barriers keep hipcc from hoisting hundreds of ds_reads (it spills otherwise).
-            f32x4 ac[3], an[3];
-            ac[0] = WX[0]; ac[1] = WX[64]; ac[2] = WX[128];
+            // k-steps of the whole step form one sequence p: x part [0, KSX), gate h part [KSX, KSX+16), candidate
+            // h part [KSX+16, KSX+32); fragments are fetched PF k-steps ahead.
+            constexpr int PF = CF_PREFETCH;
+            auto loadA = [&](int p, f32x4 (&d)[3]) {
+                if (p < KSX) { d[0] = WX[(p * 3 + 0) * 64]; d[1] = WX[(p * 3 + 1) * 64]; d[2] = WX[(p * 3 + 2) * 64]; }
+                else if (p < KSX + 16) { d[0] = WG[((p - KSX) * 2 + 0) * 64]; d[1] = WG[((p - KSX) * 2 + 1) * 64]; }
+                else if (p < KSX + 32) { d[0] = WC[(p - KSX - 16) * 64]; }
+            };
+            f32x4 ac[3], an[3], a2[3];
+            loadA(0, ac);
+            if (PF == 2) loadA(1, an);
             // x part: [r | u | c] += Wx^T x_t
 #pragma unroll
             for (int ks = 0; ks < KSX; ++ks) {
-                if (ks + 1 < KSX) {
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) an[g] = WX[((ks + 1) * 3 + g) * 64];
-                } else {
-                    an[0] = WG[0]; an[1] = WG[64];
-                }
+                if (PF == 2) loadA(ks + 2, a2); else loadA(ks + 1, an);
                 const float b = xc[ks >> 2][ks & 3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -277,7 +284,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) ac[g] = an[g];
+                for (int g = 0; g < 3; ++g) { ac[g] = an[g]; if (PF == 2) an[g] = a2[g]; }
             }
             // x_t is dead: fetch the next step's x into the same registers (clamped on the last
             // step: a harmless re-read); the h part below hides the latency.
@@ -291,11 +298,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             // h part of the gates: [r | u] += Wh_g^T h          (gru_cell/MatMul)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                if (ks + 1 < 16) {
-                    an[0] = WG[((ks + 1) * 2 + 0) * 64]; an[1] = WG[((ks + 1) * 2 + 1) * 64];
-                } else {
-                    an[0] = WC[0];
-                }
+                if (PF == 2) loadA(KSX + ks + 2, a2); else loadA(KSX + ks + 1, an);
                 const float b = h[ks >> 2][ks & 3];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
@@ -306,6 +309,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 ac[0] = an[0]; ac[1] = an[1];
+                if (PF == 2) { an[0] = a2[0]; an[1] = a2[1]; }
             }
             // r = sigmoid(.), r*h feeds the candidate matmul (reset applied BEFORE the matmul:
             // gru_cell/mul -> concat_1 -> MatMul_1)
@@ -322,7 +326,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                if (ks + 1 < 16) an[0] = WC[(ks + 1) * 64];
+                if (PF == 2) loadA(KSX + 16 + ks + 2, a2); else loadA(KSX + 16 + ks + 1, an);
                 const float b = rh[ks >> 2][ks & 3];
                 acc[8] = MFMA16(ac[0].x, b, acc[8]);
                 acc[9] = MFMA16(ac[0].y, b, acc[9]);
@@ -330,6 +334,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                 acc[11] = MFMA16(ac[0].w, b, acc[11]);
                 __builtin_amdgcn_sched_barrier(0);
                 ac[0] = an[0];
+                if (PF == 2) an[0] = a2[0];
             }
             // h' = u*h + (1-u)*c                                  (gru_cell/mul_1, sub, mul_2, add)
 #pragma unroll
