@@ -125,3 +125,18 @@ def test_fused_single_launch_matches_per_layer_launches(ckpt_weights, n_windows)
         assert np.array_equal(b.debug_stage(3, min(n_windows, 64)), a.debug_stage(3, min(n_windows, 64)))
     finally:
         a.close(); b.close()
+
+
+def test_internal_streams_option_is_bit_identical(ckpt_weights):
+    """cf_hparams.n_streams > 1 (sub-batches of one call on internal streams) gives the same bits."""
+    from catfish_amd.engine import HipEngine
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1.5, size=(5000, 35)).astype(np.float32)
+    a = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096, n_streams=1)
+    b = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096, n_streams=3)
+    try:
+        ref = a.infer_host(x)
+        for _ in range(3):
+            assert np.array_equal(b.infer_host(x), ref)
+    finally:
+        a.close(); b.close()

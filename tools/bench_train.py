@@ -19,11 +19,16 @@ import bench  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256, help="windows per training batch (the reference trains with 256)")
+    args = ap.parse_args()
+    B = args.batch
     w = bench.load_weights()
-    reads = bench.make_reads(8, seed=5).reshape(-1, 35)
+    reads = bench.make_reads(max(8, B // 100 + 1), seed=5).reshape(-1, 35)
     rng = np.random.default_rng(0)
-    x = reads[rng.permutation(len(reads))[:256]]
-    y = np.repeat((np.arange(256) % 2)[:, None], 35, axis=1).astype(np.float32)
+    x = reads[rng.permutation(len(reads))[:B]]
+    y = np.repeat((np.arange(B) % 2)[:, None], 35, axis=1).astype(np.float32)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     gpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)     # native HIP biGRU kernels on a GPU
     cpu = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
@@ -56,7 +61,7 @@ def main():
             modes[name + "_ms_per_step"] = (time.perf_counter() - t1) / 5 * 1e3
     print(json.dumps({"metric": "training windows/s (config 5: native HIP biGRU fwd/bwd + torch autograd for the rest, TF-style Adam)",
                       "device": dev, "native": bool(getattr(tr, "native", False)), "other_modes": modes,
-                      "value": n * 256 / dt, "ms_per_step": dt / n * 1e3,
+                      "batch": B, "value": n * B / dt, "ms_per_step": dt / n * 1e3,
                       "loss_10_steps_device": lg, "loss_10_steps_cpu": lc,
                       "max_loss_diff": float(np.max(np.abs(np.array(lg) - np.array(lc))))}))
 
