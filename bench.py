@@ -123,7 +123,7 @@ def main():
     torch.cuda.synchronize()
 
     if not args.no_kernel_events:
-        eng.profile_enable(True)
+        eng.profile_enable(True, every=4)        # HIP events around every kernel of every 4th step of the timed region
         eng.profile_reset()
     barrier()
     torch.cuda.synchronize()

@@ -718,7 +718,9 @@ struct cf_model {
     hipEvent_t fork = nullptr;
     int64_t ws_bytes = 0;
     // profiling
-    bool prof = false;
+    bool prof = false;                    // events around the kernels of THIS call (set per cf_infer from prof_every)
+    int prof_every = 0;                   // 0 = off, N = time every N-th cf_infer call
+    int64_t prof_calls = 0;
     struct Ev { hipEvent_t a, b; int slot; };
     std::vector<Ev> ev_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -1214,6 +1216,7 @@ extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* p
                                 "(create the model with fuse_layers = -1)");
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    m->prof = m->prof_every > 0 && (m->prof_calls++ % m->prof_every) == 0;
     const int n_slots = (int)m->slots.size();
     // sub-batch size: split the call evenly over the slots, in whole 8-tile groups (128 windows)
     int64_t chunk = m->cap_windows;
@@ -1428,8 +1431,10 @@ static int prof_collect(cf_model* m) {
 }
 extern "C" int cf_profile_enable(cf_model* m, int on) {
     if (!m) return fail(CF_ERR_INVALID, "null model");
-    if (!on && m->prof) { int rc = prof_collect(m); if (rc != CF_OK) return rc; }
+    if (!on && m->prof_every) { int rc = prof_collect(m); if (rc != CF_OK) return rc; }
+    m->prof_every = on < 0 ? 0 : on;
     m->prof = on != 0;
+    m->prof_calls = 0;
     return CF_OK;
 }
 extern "C" int cf_profile_reset(cf_model* m) {

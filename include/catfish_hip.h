@@ -168,8 +168,8 @@ int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, cons
                           const float* dy_frag, float* dx_frag, float* da, int64_t n_windows, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
- * roofline report.  cf_profile_enable(m, 1) makes every cf_infer record
- * events around each kernel; cf_profile_read synchronises and returns, for
+ * roofline report.  cf_profile_enable(m, N) makes every N-th cf_infer call
+ * (N = 1: every call; 0 = off) record events around each of its kernels; cf_profile_read synchronises and returns, for
  * kernel slot k, the accumulated milliseconds and launch count since the
  * last cf_profile_reset. */
 #define CF_PROF_SLOTS 12
