@@ -140,3 +140,25 @@ def test_internal_streams_option_is_bit_identical(ckpt_weights):
             assert np.array_equal(b.infer_host(x), ref)
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("n_layers,n_layers_res", [(1, 1), (2, 3), (4, 2), (1, 0), (2, 0)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_other_depths(n_layers, n_layers_res, precision):
+    """Any number of biGRU layers / residual blocks (the reference's random search draws 1-6 and 1-12,
+    networks/train_validate.py:67-111); widths stay 64 / 32."""
+    from catfish_amd.engine import HipEngine
+    if n_layers_res == 0 and precision != "fp32":
+        pytest.skip("plain RNN type is fp32 only")
+    w = oracle.random_weights(seed=7 * n_layers + n_layers_res, n_layers=n_layers, n_layers_res=n_layers_res)
+    rng = np.random.default_rng(3)
+    for n in (50, 3000):                       # cooperative small-call kernels and the throughput kernels
+        x = rng.normal(0, 1.3, size=(n, 35)).astype(np.float32)
+        eng = HipEngine(w, n_layers=n_layers, n_layers_res=n_layers_res, device=0, max_windows_per_pass=4096,
+                        precision=precision)
+        try:
+            got = eng.infer_host(x)
+        finally:
+            eng.close()
+        want = oracle.forward(x, w, np.float64, n_layers=n_layers, n_layers_res=n_layers_res)
+        assert np.abs(got - want).max() < 1e-4, (n, np.abs(got - want).max())
