@@ -97,8 +97,22 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # The data path has no collective; the process group only serves the timing barrier and the MAX over
+        # ranks.  RCCL ("nccl") first; if it cannot initialise on this node, fall back to gloo (host barrier).
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.zeros(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            backend = "nccl"
+        except Exception as exc:      # pragma: no cover - depends on the node
+            sys.stderr.write("bench.py: nccl init failed (%s); using gloo for the timing barrier\n" % exc)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
+            backend = "gloo"
 
     from catfish_amd.engine import HipEngine
     weights = load_weights()
@@ -137,7 +151,7 @@ def main():
     eng.profile_enable(False)
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -713,6 +713,9 @@ struct cf_model {
     std::vector<Slot> slots;
     int fuse = 0;                             // all GRU layers in one launch (fp32 path, n_layers <= 3): 0 never, 1 always,
                                               // 2 auto = only for passes of >= 6 rounds, where the dynamic queues pay
+    float* d_host_x = nullptr;                // cf_infer_host staging (grown on demand)
+    float* d_host_p = nullptr;
+    size_t host_stage_bytes = 0;
     unsigned* h_err = nullptr;                // host-mapped: set by a fused launch whose bounded wait timed out (sticky)
     unsigned* d_err = nullptr;                // device view of h_err
     hipEvent_t fork = nullptr;
@@ -871,6 +874,8 @@ extern "C" void cf_model_destroy(cf_model* m) {
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (m->d_host_x) (void)hipFree(m->d_host_x);
+    if (m->d_host_p) (void)hipFree(m->d_host_p);
     if (m->h_err) (void)hipHostFree(m->h_err);
     if (m->fork) (void)hipEventDestroy(m->fork);
     for (auto& e : m->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1262,18 +1267,26 @@ extern "C" int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, flo
     if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer_host: null buffer");
     HIP_TRY(hipSetDevice(m->device));
     const size_t bytes = (size_t)n_windows * CF_T * sizeof(float);
-    float *dx = nullptr, *dp = nullptr;
-    HIP_TRY(hipMalloc((void**)&dx, bytes));
-    hipError_t e = hipMalloc((void**)&dp, bytes);
-    if (e != hipSuccess) { (void)hipFree(dx); return fail(CF_ERR_NOMEM, "cf_infer_host: hipMalloc failed"); }
+    // device staging buffers are kept across calls (the reference calls infer once per read)
+    if (m->host_stage_bytes < bytes) {
+        if (m->d_host_x) (void)hipFree(m->d_host_x);
+        if (m->d_host_p) (void)hipFree(m->d_host_p);
+        m->d_host_x = m->d_host_p = nullptr;
+        m->host_stage_bytes = 0;
+        const size_t cap = bytes + bytes / 4;
+        HIP_TRY(hipMalloc((void**)&m->d_host_x, cap));
+        hipError_t e2 = hipMalloc((void**)&m->d_host_p, cap);
+        if (e2 != hipSuccess) { (void)hipFree(m->d_host_x); m->d_host_x = nullptr; return fail(CF_ERR_NOMEM, "cf_infer_host: hipMalloc failed"); }
+        m->host_stage_bytes = cap;
+    }
+    float *dx = m->d_host_x, *dp = m->d_host_p;
+    hipError_t e = hipSuccess;
     int rc = CF_OK;
     if ((e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
     if (rc == CF_OK) rc = cf_infer(m, dx, n_windows, dp, nullptr);
     if (rc == CF_OK && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
     if (rc == CF_OK && m->h_err && *m->h_err) rc = fail(CF_ERR_HIP, "fused GRU launch timed out waiting for a producer workgroup");
     if (rc == CF_OK && (e = hipMemcpy(probs, dp, bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
-    (void)hipFree(dx);
-    (void)hipFree(dp);
     return rc;
 }
 

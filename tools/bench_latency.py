@@ -22,5 +22,14 @@ for prec in ("fp32", "bf16x3", "bf16"):
             eng.infer_device(x, out=y)
             torch.cuda.synchronize()
         out["%s_%d_windows_ms" % (prec, n)] = (time.perf_counter() - t0) / reps * 1e3
+    if prec == "fp32":
+        import numpy as np
+        xh = np.random.default_rng(0).normal(size=(118, 35, 1))
+        for _ in range(5):
+            eng.infer_host(xh)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            eng.infer_host(xh)
+        out["fp32_118_windows_host_numpy_in_out_ms"] = (time.perf_counter() - t0) / 50 * 1e3
     eng.close()
 print(json.dumps(out))
