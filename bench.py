@@ -86,6 +86,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "CATFISH_BENCH_DEVICE" in os.environ:      # rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+        local_rank = int(os.environ["CATFISH_BENCH_DEVICE"])
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_res = cpu_baseline()
