@@ -296,3 +296,40 @@ def test_native_trainer_follows_the_torch_trainer():
     assert np.allclose(la, lb, rtol=0, atol=2e-4), (la, lb)
     assert la[-1] < la[0]
     a.engine.close()
+
+
+def test_cli_end_to_end(tmp_path, ckpt_weights, monkeypatch):
+    """`catfish -i IN -s OUT -c 300` (catfish/catfish:18-94): model directory with ResNetRNN.txt + a TF
+    checkpoint-V2 bundle (written here from the exported tensors), a directory of reads, chunk coordinates out."""
+    import json
+    from click.testing import CliRunner
+    from catfish_amd import checkpoint, cli
+    net = tmp_path / "ResNetRNN"
+    (net / "checkpoints").mkdir(parents=True)
+    (net / "ResNetRNN.txt").write_text("MODEL TYPE: ResNet-RNN\n\nbatch_size: 256\noptimizer_choice: RMSProp\n"
+                                       "learning_rate: 0.001\nlayer_size: 64\nn_layers: 3\nkeep_prob: 0.8\n"
+                                       "layer_size_res: 32\nn_layers_res: 2\n")
+    checkpoint.write_checkpoint(str(net / "checkpoints" / "ckpnt-30000"), ckpt_weights)
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    dacs = {}
+    for i, n in enumerate((4096, 2500, 700)):
+        d = oracle.synthetic_dac(1, n, seed=500 + i)[0]
+        np.save(reads / ("read%d.npy" % i), d)
+        dacs["read%d.npy" % i] = d
+    monkeypatch.chdir(tmp_path)                      # the reference resolves "ResNetRNN" relative to the CWD (:44)
+    res = CliRunner().invoke(cli._build_click_main(), ["-i", str(reads), "-s", str(tmp_path / "out"), "-c", "300"])
+    assert res.exit_code == 0, res.output
+    hp = json.load(open(tmp_path / "out" / "TEMP" / "hp_positions.json"))
+    nonhp = json.load(open(tmp_path / "out" / "TEMP" / "nonhp_positions.json"))
+    for name, d in dacs.items():
+        spans, length, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
+        if spans:
+            merged = cli.merge_positions([list(s) for s in spans], length, 300)
+            assert hp[name] == merged
+            assert nonhp[name] == cli.nonhp_complement(merged, length)
+        else:
+            assert name not in hp
+    # second run into the same directory fails like the reference (os.makedirs on an existing TEMP/HP)
+    res2 = CliRunner().invoke(cli._build_click_main(), ["-i", str(reads), "-s", str(tmp_path / "out")])
+    assert res2.exit_code != 0
