@@ -490,6 +490,9 @@ __global__ __launch_bounds__(512, 2) void gru_fused_kernel(cf_fused_args a) {
 #define CF_COOP_XCH_FLOATS (2 * 4 * 64 * 4 + 4 * 64)   // LDS exchange area of the cooperative kernel: h, r*h, dense partials
 #include "gru_coop.hpp"
 #include "gru_train.hpp"
+static_assert(gtb_pack_floats(32) == ((32 + CF_H) / 16 / 2) * 128 * 48 && gtb_pack_floats(128) == ((128 + CF_H) / 16 / 2) * 128 * 48,
+              "gru_train_bwd_coop_kernel's PACK must equal gtb_pack_floats");
+#define CF_COOP_BWD_XCH_FLOATS (3 * 4 * 64 * 4)   // da_c, da_r, da_u exchange tiles
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1b: plain RNN type (no residual blocks, rnn_class.py:165-175 applied to the raw signal).
@@ -999,6 +1002,10 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_layer_coop_kernel<32, true>, (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4);
         optin((const void*)gru_layer_coop_kernel<128, false>, (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4);
         optin((const void*)gru_layer_coop_kernel<128, true>, (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_train_fwd_coop_kernel<32>, (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_train_fwd_coop_kernel<128>, (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4);
+        optin((const void*)gru_train_bwd_coop_kernel<32>, (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4);
+        optin((const void*)gru_train_bwd_coop_kernel<128>, (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4);
         optin((const void*)gru_train_fwd_kernel<32>, gru_pack_floats(32) * 4);
         optin((const void*)gru_train_fwd_kernel<128>, gru_pack_floats(128) * 4);
         optin((const void*)gru_train_bwd_kernel<32>, gtb_pack_floats(32) * 4);
@@ -1392,6 +1399,17 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    if (2 * n_tiles <= m->n_cu) {            // small batch: four waves per tile (latency mode)
+        const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
+        if (cin == CF_C)
+            hipLaunchKernelGGL((gru_train_fwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
+                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+        else
+            hipLaunchKernelGGL((gru_train_fwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
+                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+        HIP_TRY(hipGetLastError());
+        return CF_OK;
+    }
     const int waves = pick_waves(2 * n_tiles, m->n_cu);
     const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
     if (cin == CF_C)
@@ -1414,6 +1432,19 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    if (2 * n_tiles <= m->n_cu) {            // small batch: four waves per tile (latency mode)
+        const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
+        if (cin == CF_C)
+            hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
+                               wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
+                               reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+        else
+            hipLaunchKernelGGL((gru_train_bwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
+                               wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
+                               reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+        HIP_TRY(hipGetLastError());
+        return CF_OK;
+    }
     const int waves = pick_waves(2 * n_tiles, m->n_cu);
     const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
     if (cin == CF_C)

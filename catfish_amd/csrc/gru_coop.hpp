@@ -11,9 +11,10 @@
 template <int W>
 __device__ __forceinline__ float pick4(const f32x4& a) { return a[W]; }
 
-template <int CIN, bool LAST, int W>
+template <int CIN, bool LAST, int W, bool STASH = false>
 __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ X,
-                                              f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles) {
+                                              f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
+                                              f32x4* __restrict__ S = nullptr) {
     constexpr int KGX = CIN / 16;
     constexpr int KSX = CIN / 4;
     constexpr int XN4 = gru_x_floats(CIN) / 4;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
         }
         f32x4 rh;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rh[r] = cf_sigmoid_pre(ar[r]) * hown[r];
+        for (int r = 0; r < 4; ++r) { ar[r] = cf_sigmoid_pre(ar[r]); rh[r] = ar[r] * hown[r]; }
         rx[W * 64] = rh;
         __syncthreads();
         f32x4 rf[4];
@@ -95,6 +96,11 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
             const float u = cf_sigmoid_pre(au[r]);
             const float c = cf_tanh_pre(acnd[r]);
             hown[r] = fmaf(u, hown[r] - c, c);
+            if constexpr (STASH) { au[r] = u; acnd[r] = c; }
+        }
+        if constexpr (STASH) {      // training forward: activated r, u, c of this wave's 16 hidden units
+            f32x4* sdst = S + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
+            sdst[(0 + W) * 64] = ar; sdst[(4 + W) * 64] = au; sdst[(8 + W) * 64] = acnd;
         }
         hx[W * 64] = hown;
         if constexpr (!LAST) {
@@ -140,5 +146,145 @@ __global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __r
             default: gru_tile_coop<CIN, LAST, 3>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
         }
         __syncthreads();
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
+                                                                    f32x4* __restrict__ Y, f32x4* __restrict__ S, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK = gru_pack_floats(CIN);
+    const int dir = blockIdx.y;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 8
+        for (int i = threadIdx.x; i < PACK / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xch = lds + PACK;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        switch (wave) {
+            case 0: gru_tile_coop<CIN, false, 0, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+            case 1: gru_tile_coop<CIN, false, 1, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+            case 2: gru_tile_coop<CIN, false, 2, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+            default: gru_tile_coop<CIN, false, 3, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cooperative BPTT (small training batches): four waves per tile.  Wave W owns hidden units 16W..16W+15
+// (dh, du, dc, the three pre-activation gradients of those units) and the output M-tiles {h-row tile W,
+// x-row tiles W, W+4, ...} of both backward products; the pre-activation gradients of all 64 units are
+// exchanged through 12 KiB of LDS (three barriers per step).  Same arithmetic per element as
+// gru_train_bwd_kernel.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int W>
+__device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ Y,
+                                                  const f32x4* __restrict__ S, const f32x4* __restrict__ DY, f32x4* __restrict__ DX,
+                                                  f32x4* __restrict__ DA, int n_tiles) {
+    constexpr int MI = (CIN + CF_H) / 16;
+    constexpr int MX = CIN / 16;
+    constexpr int NXW = MX > W ? (MX - W + 3) / 4 : 0;          // x-row tiles of this wave: W, W+4, ...
+    constexpr int CF2 = 16 * (MI / 2) * 64;                     // candidate region in f32x2 units
+    const f32x2* WCt = reinterpret_cast<const f32x2*>(lds) + lane;
+    const f32x2* WGt = WCt + CF2;
+    f32x4* XC = reinterpret_cast<f32x4*>(xch) + lane;           // da_c tiles [4][64]
+    f32x4* XR = XC + 4 * 64;                                    // da_r
+    f32x4* XU = XR + 4 * 64;                                    // da_u
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+    f32x4 dhc = {0, 0, 0, 0};
+    for (int s = CF_T - 1; s >= 0; --s) {
+        const int t = dir ? (CF_T - 1 - s) : s;
+        const int tp = dir ? (t + 1) : (t - 1);
+        const int64_t base = (int64_t)tile * CF_T + t;
+        const f32x4* sp = S + (base * 2 + dir) * 12 * 64 + lane;
+        const f32x4 r = sp[(0 + W) * 64], u = sp[(4 + W) * 64], c = sp[(8 + W) * 64];
+        const f32x4 dh = dhc + DY[(base * 8 + dir * 4 + W) * 64 + lane];
+        f32x4 hp = {0, 0, 0, 0};
+        if (s > 0) hp = Y[(((int64_t)tile * CF_T + tp) * 8 + dir * 4 + W) * 64 + lane];
+        const f32x4 du = dh * (hp - c);
+        const f32x4 dac = dh * (one - u) * (one - c * c);
+        const f32x4 dau = du * u * (one - u);
+        dhc = dh * u;
+        XC[W * 64] = dac;
+        XU[W * 64] = dau;
+        __syncthreads();
+        f32x4 dacf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dacf[m] = XC[m * 64];
+        f32x4 dx[NXW > 0 ? NXW : 1];
+#pragma unroll
+        for (int i = 0; i < (NXW > 0 ? NXW : 1); ++i) dx[i] = (f32x4){0, 0, 0, 0};
+        f32x4 drh = {0, 0, 0, 0}, dhg = {0, 0, 0, 0};
+        constexpr int HT = MX + W;                                // this wave's h-row tile
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float b = dacf[ks >> 2][ks & 3];
+            drh = MFMA16(WCt[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, drh);
+#pragma unroll
+            for (int i = 0; i < NXW; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int xt = W + 4 * i;
+                dx[i] = MFMA16(WCt[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const f32x4 dar = drh * hp * r * (one - r);
+        dhc += drh * r;
+        XR[W * 64] = dar;
+        __syncthreads();
+        f32x4 dag[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { dag[m] = XR[m * 64]; dag[4 + m] = XU[m * 64]; }
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const float b = dag[ks >> 2][ks & 3];
+            dhg = MFMA16(WGt[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, dhg);
+#pragma unroll
+            for (int i = 0; i < NXW; ++i) {
+                const int xt = W + 4 * i;
+                dx[i] = MFMA16(WGt[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dhc += dhg;
+#pragma unroll
+        for (int i = 0; i < NXW; ++i)
+            DX[(((int64_t)dir * n_tiles * CF_T + base) * MX + (W + 4 * i)) * 64 + lane] = dx[i];
+        f32x4* dap = DA + (base * 2 + dir) * 12 * 64 + lane;
+        dap[(0 + W) * 64] = dar; dap[(4 + W) * 64] = dau; dap[(8 + W) * 64] = dac;
+        __syncthreads();                                           // the exchange area is rewritten by the next step
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ Y,
+                                                                    const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
+                                                                    f32x4* __restrict__ DX, f32x4* __restrict__ DA, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK = ((CIN + CF_H) / 16 / 2) * 128 * 48;      // = gtb_pack_floats(CIN)
+    const int dir = blockIdx.y;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wpack + (size_t)dir * PACK);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 8
+        for (int i = threadIdx.x; i < PACK / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xch = lds + PACK;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        switch (wave) {
+            case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
+            case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
+            case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
+            default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
+        }
     }
 }
