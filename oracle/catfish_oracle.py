@@ -14,19 +14,23 @@ reference repository root).
 
 Pinning status
 --------------
-* Network forward (``forward``): **parity unpinned**.  The arithmetic lives in
-  TensorFlow 1.10.0 (third-party, pinned only by ``tensorflow_version`` inside
-  ckpnt-30000.meta; not importable here, not installable, no wheel for this
-  interpreter) and the reference ships no tests, golden vectors or recorded
-  outputs for this path.  The restatement follows the reference's call sites
-  (resnet_class.py:44-82, rnn_class.py:142-183,82-88,213-219) and the
-  published TF-1.10 semantics of ``tf.layers.conv1d`` (cross-correlation,
-  SAME zero padding), ``tf.layers.batch_normalization`` (inference mode,
-  epsilon 1e-3), ``tf.contrib.rnn.GRUCell`` (gate order [r, u]; reset applied
-  to the state BEFORE the candidate matmul; ``h' = u*h + (1-u)*c``),
-  ``stack_bidirectional_dynamic_rnn`` (per layer: fw on the sequence, bw on
-  the time-reversed sequence, outputs re-reversed and concatenated [fw, bw]),
-  ``tf.layers.dense`` and ``tf.nn.sigmoid``.
+* Network forward (``forward``): **graph pinned, op arithmetic unpinned**.  The
+  reference ships the MetaGraphDef its TensorFlow-1.10 session executed
+  (ckpnt-30000.meta).  ``oracle/tf_graph.py`` decodes it (wire-format parser,
+  nothing executed) and interprets its inference subgraph node by node;
+  ``forward`` agrees with that interpretation to 1e-10 in fp64 on the bundled
+  checkpoint and on random variables, stage by stage
+  (tests/test_reference_graph.py, vectors in tests/golden/graph_golden.npz from
+  tests/golden/make_graph_golden.py).  That pins everything the reference's own
+  file can pin: op order, every attribute (SAME padding, unit strides, NHWC,
+  split into [r, u], reset applied to the state BEFORE the candidate matmul,
+  ``h' = u*h + (1-u)*c``, bw = reverse -> run -> reverse, concat [fw, bw],
+  unfused inference batch norm with float32 epsilon 1e-3, dropout wiring), and
+  which variable feeds which op.  What stays a restatement is the arithmetic of
+  the individual TF op kernels (Conv2D, MatMul, Sigmoid, Tanh ...): TensorFlow
+  1.10.0 is third-party, not importable here and not installable, and the
+  reference ships no tests or recorded outputs of a real TF run -- in that
+  sense parity with an actual TF execution remains **parity unpinned**.
 * Checkpoint reader: pinned by the per-tensor masked CRC-32C values stored in
   ckpnt-30000.index (tests/test_checkpoint.py).
 * Pre/post-processing (``normalize_raw_signal``, ``pad_and_window``,

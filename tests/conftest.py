@@ -34,6 +34,13 @@ def golden_read():
 
 
 @pytest.fixture(scope="session")
+def graph_golden():
+    """Outputs of the reference's own MetaGraphDef, interpreted in numpy (make_graph_golden.py)."""
+    with np.load(os.path.join(GOLDEN, "graph_golden.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
 def hp():
     return dict(batch_size=256, optimizer_choice="RMSProp", learning_rate=0.001, layer_size=64,
                 n_layers=3, keep_prob=0.8, layer_size_res=32, n_layers_res=2)

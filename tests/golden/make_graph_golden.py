@@ -1,0 +1,116 @@
+"""Golden vectors from the reference's OWN TensorFlow graph.
+
+Reads ``catfish/ResNetRNN/checkpoints/ckpnt-30000.meta`` (the MetaGraphDef the reference's
+TF-1.10 session ran, saved at rnn_class.py:48 / restored at rnn_class.py:191-198) with the
+wire-format parser in ``oracle/tf_graph.py`` -- nothing from the file is executed -- and
+evaluates its inference subgraph ``data/Placeholder -> accuracy/Sigmoid`` (rnn_class.py:84,
+213-216), the loss ``loss/Mean`` (rnn_class.py:74-79) and ``accuracy/Mean`` node by node in numpy,
+with the variables of ``ckpnt-30000`` and with a seeded random weight set.
+
+Run in the build container (needs /root/reference):   python tests/golden/make_graph_golden.py
+Writes tests/golden/graph_golden.npz and tests/golden/graph_summary.json.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from catfish_amd import checkpoint            # noqa: E402  (bundle reader, pinned by the bundle's own CRC-32Cs)
+from oracle import catfish_oracle as O        # noqa: E402  (only for the seeded random weight set)
+from oracle import tf_graph as G              # noqa: E402
+
+REF = os.environ.get("CATFISH_REFERENCE", "/root/reference")
+PREFIX = os.path.join(REF, "catfish", "ResNetRNN", "checkpoints", "ckpnt-30000")
+FETCH = "accuracy/Sigmoid"
+STAGES = {
+    "res0": "ResNet_layer_0/residual_block/Relu_3",
+    "res1": "ResNet_layer_1/residual_block/Relu_3",
+    "gru0": "recurrent_layer/stack_bidirectional_rnn/cell_0/concat",
+    "gru1": "recurrent_layer/stack_bidirectional_rnn/cell_1/concat",
+    "gru2": "recurrent_layer/stack_bidirectional_rnn/cell_2/concat",
+    "logits": "Reshape_1",
+}
+RANDOM_SEED = 3
+STAGE_WINDOWS = 8
+
+
+def make_inputs():
+    rng = np.random.RandomState(20260101)
+    x = (rng.randn(96, 35) * 1.5).astype(np.float32)
+    x[5] = 0.0                                  # an all-padding window
+    x[6, 20:] = 0.0                             # a ragged tail (infer.py:31-38 zero padding)
+    x[7] *= 8.0                                 # saturating activations
+    y = (rng.rand(96, 35, 1) < 0.3).astype(np.float32)
+    return x, y
+
+
+def run(nodes, variables, x, y, dtype):
+    gi = G.GraphInterpreter(nodes, variables, dtype)
+    feeds = {"data/Placeholder": x.reshape(-1, 35, 1), "data/Placeholder_1": y, "dropout": np.float32(1.0)}
+    out = {"probs": np.asarray(gi.run(FETCH, feeds)).reshape(-1)}
+    for k, node in STAGES.items():
+        out[k] = np.asarray(gi.run(node, feeds))
+    out["loss"] = np.asarray(gi.run("loss/Mean", feeds))
+    out["accuracy"] = np.asarray(gi.run("accuracy/Mean", feeds))
+    return out, gi.ops_used
+
+
+def summary(nodes):
+    sub = G.inference_subgraph(nodes, FETCH)
+    ops = {}
+    for n in sub:
+        ops[nodes[n].op] = ops.get(nodes[n].op, 0) + 1
+    pick = lambda nd, keys: {k: nd.attr.get(k) for k in keys}     # noqa: E731
+    convs = {n: pick(nodes[n], ("padding", "strides", "data_format", "dilations")) for n in sub if nodes[n].op == "Conv2D"}
+    kernels = {n: [s for s, _ in nodes[n].inputs] for n in sub if nodes[n].op in ("Conv2D", "MatMul")}
+    splits = {n: int(nodes[n].attr["num_split"]) for n in sub if nodes[n].op == "Split"}
+    consts = {}
+    for n in sub:
+        nd = nodes[n]
+        if nd.op == "Const" and (n.endswith("batchnorm/add/y") or n.endswith("split/split_dim") or n.endswith("concat/axis")
+                                 and "gru_cell" in n):
+            consts[n] = np.asarray(nd.attr["value"]).tolist()
+    opt = {n: float(np.asarray(nodes[n].attr["value"])) for n in nodes
+           if n.startswith("optimizer/RMSProp/") and nodes[n].op == "Const" and n.count("/") == 2}
+    return {"meta_info": G.meta_info(PREFIX + ".meta"), "fetch": FETCH, "n_nodes_total": len(nodes), "n_nodes_inference": len(sub),
+            "ops_inference": dict(sorted(ops.items())),
+            "variables_inference": sorted(n for n in sub if nodes[n].op == "VariableV2"),
+            "conv2d_attrs": convs, "matmul_conv_inputs": kernels, "split_num": splits, "constants": consts,
+            "optimizer_constants": opt, "stage_nodes": STAGES}
+
+
+def main():
+    nodes = G.load_meta_graph(PREFIX + ".meta")
+    variables = checkpoint.read_checkpoint(PREFIX)
+    x, y = make_inputs()
+    arrays = {"x": x, "y": y}
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        out, used = run(nodes, variables, x, y, dt)
+        for k, v in out.items():
+            if k in STAGES and k != "logits":
+                if tag != "f64":
+                    continue
+                v = v[:STAGE_WINDOWS]                   # per-stage activations of the first windows only (file size)
+            arrays["ckpt_%s_%s" % (tag, k)] = v
+    rnd = dict(variables)
+    rnd.update(O.random_weights(seed=RANDOM_SEED))
+    out, _ = run(nodes, rnd, x, y, np.float64)
+    arrays["rand_f64_probs"] = out["probs"]
+    arrays["rand_f64_loss"] = out["loss"]
+    arrays["random_seed"] = np.int64(RANDOM_SEED)
+    np.savez_compressed(os.path.join(HERE, "graph_golden.npz"), **arrays)
+    sm = summary(nodes)
+    sm["ops_executed"] = dict(sorted(used.items()))
+    with open(os.path.join(HERE, "graph_summary.json"), "w") as fh:
+        json.dump(sm, fh, indent=1, sort_keys=True, default=lambda o: list(o) if isinstance(o, tuple) else str(o))
+    print("wrote graph_golden.npz (%d arrays), graph_summary.json; loss=%.6f acc=%.4f"
+          % (len(arrays), float(arrays["ckpt_f64_loss"]), float(arrays["ckpt_f64_accuracy"])))
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,19 @@ def test_golden_read_probs(engine, golden_read):
     assert np.mean((probs >= 0.5) == (golden_read["probs_fp32"] >= 0.5)) == 1.0
 
 
+def test_hip_path_matches_reference_graph(engine, graph_golden):
+    """The HIP path against the outputs of the reference's own TF graph (ckpnt-30000.meta interpreted in
+    numpy, tests/golden/make_graph_golden.py) -- no oracle in between."""
+    probs = engine.infer_host(graph_golden["x"])
+    assert np.abs(probs.astype(np.float64) - graph_golden["ckpt_f64_probs"]).max() < TOL
+    assert np.abs(probs - graph_golden["ckpt_f32_probs"]).max() < 2e-5
+    for stage, key in ((0, "res0"), (1, "res1"), (2, "gru0"), (3, "gru1")):
+        ref = graph_golden["ckpt_f64_" + key]
+        got = engine.debug_stage(stage, ref.shape[0])
+        assert got.shape == ref.shape, key
+        assert np.allclose(got, ref, rtol=2e-5, atol=2e-5), "stage %s max err %g" % (key, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize("n_windows", [1, 15, 16, 17, 127, 128, 129, 1000])
 def test_ragged_window_counts_random_weights(n_windows):
     """Random weights (non-trivial BN stats/biases) and ragged tile/workgroup tails."""

@@ -1,0 +1,100 @@
+"""The oracle (and the torch training restatement) against the reference's OWN TensorFlow graph.
+
+``tests/golden/graph_golden.npz`` holds the outputs of the MetaGraphDef the reference ships
+(ckpnt-30000.meta), interpreted node by node in numpy (``oracle/tf_graph.py``,
+generator ``tests/golden/make_graph_golden.py``).  The graph's structure and attributes are the
+reference's; only the per-op arithmetic is restated.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REFERENCE, has_reference
+from oracle import catfish_oracle as oracle
+
+
+@pytest.fixture(scope="module")
+def graph_summary():
+    with open(os.path.join(GOLDEN, "graph_summary.json")) as fh:
+        return json.load(fh)
+
+
+def test_oracle_matches_reference_graph_fp64(ckpt_weights, graph_golden):
+    """Exact-arithmetic value of the reference graph vs the fp64 oracle (bundled checkpoint).
+
+    The only known difference is the BN epsilon: the graph holds float32(1e-3) = 0.0010000000475, the
+    oracle the double 1e-3 -> ~1e-10 on the probabilities.
+    """
+    p, st = oracle.forward(graph_golden["x"], ckpt_weights, np.float64, return_stages=True)
+    assert np.abs(p - graph_golden["ckpt_f64_probs"]).max() < 1e-9
+    assert np.abs(st["logits"] - graph_golden["ckpt_f64_logits"].reshape(-1)).max() < 1e-7
+    n = graph_golden["ckpt_f64_res0"].shape[0]
+    for k in ("res0", "res1", "gru0", "gru1", "gru2"):
+        ref = graph_golden["ckpt_f64_" + k]
+        assert st[k][:n].shape == ref.shape, k
+        assert np.allclose(st[k][:n], ref, rtol=2e-8, atol=1e-8), k
+
+
+def test_oracle_matches_reference_graph_fp32(ckpt_weights, graph_golden):
+    """The graph run in float32 (as TF does) vs the fp32 oracle: rounding-order differences only."""
+    p = oracle.forward(graph_golden["x"], ckpt_weights, np.float32)
+    assert np.abs(p - graph_golden["ckpt_f32_probs"]).max() < 5e-6
+    assert np.abs(graph_golden["ckpt_f32_probs"] - graph_golden["ckpt_f64_probs"]).max() < 5e-6
+
+
+def test_oracle_matches_reference_graph_random_weights(graph_golden):
+    """Same graph, seeded random variables: a structure check that does not depend on the trained values."""
+    w = oracle.random_weights(seed=int(graph_golden["random_seed"]))
+    p = oracle.forward(graph_golden["x"], w, np.float64)
+    assert np.abs(p - graph_golden["rand_f64_probs"]).max() < 1e-9
+
+
+def test_graph_summary_matches_what_the_kernels_assume(graph_summary):
+    """Attributes the HIP kernels hard-code, as they stand in the reference's graph."""
+    assert graph_summary["meta_info"]["tensorflow_version"] == "1.10.0"
+    assert len(graph_summary["variables_inference"]) == 74
+    assert len(graph_summary["conv2d_attrs"]) == 8
+    for name, at in graph_summary["conv2d_attrs"].items():
+        assert at["padding"] == "SAME" and at["strides"] == [1, 1, 1, 1] and at["data_format"] == "NHWC", name
+    eps = [v for k, v in graph_summary["constants"].items() if k.endswith("batchnorm/add/y")]
+    assert len(eps) == 8 and all(abs(e - 1e-3) < 1e-9 for e in eps)
+    assert set(graph_summary["split_num"].values()) == {2} and len(graph_summary["split_num"]) == 6
+    ops = graph_summary["ops_inference"]
+    assert ops["Exit"] == 6 and ops["ReverseV2"] == 6 and ops["MatMul"] == 13 and ops["Sigmoid"] == 7 and ops["Tanh"] == 6
+    opt = graph_summary["optimizer_constants"]
+    assert abs(opt["optimizer/RMSProp/learning_rate"] - 1e-3) < 1e-9
+    assert abs(opt["optimizer/RMSProp/decay"] - 0.9) < 1e-7 and opt["optimizer/RMSProp/momentum"] == 0.0
+    assert abs(opt["optimizer/RMSProp/epsilon"] - 1e-10) < 1e-16
+
+
+def test_training_loss_and_accuracy_match_reference_graph(ckpt_weights, graph_golden):
+    """loss/Mean and accuracy/Mean of the reference graph vs catfish_amd.training / catfish_amd.metrics."""
+    import torch
+    from catfish_amd.training import TorchResNetRNN
+    net = TorchResNetRNN(ckpt_weights, 3, 2, device="cpu", dtype=torch.float64)
+    x = torch.from_numpy(graph_golden["x"]).to(torch.float64)
+    y = torch.from_numpy(graph_golden["y"].reshape(-1, 35)).to(torch.float64)
+    loss = float(net.loss(x, y))
+    assert abs(loss - float(graph_golden["ckpt_f64_loss"])) < 1e-9
+    p = oracle.forward(graph_golden["x"], ckpt_weights, np.float64)
+    acc = np.mean(np.round(p) == graph_golden["y"].reshape(-1))
+    assert abs(acc - float(graph_golden["ckpt_f64_accuracy"])) < 1e-6
+
+
+@pytest.mark.skipif(not has_reference(), reason="needs /root/reference (build container only)")
+def test_golden_regenerates_from_the_reference_meta_graph(graph_golden):
+    """Re-interpret the reference's .meta live and compare with the committed vectors."""
+    from catfish_amd import checkpoint
+    from oracle import tf_graph
+    prefix = os.path.join(REFERENCE, "catfish", "ResNetRNN", "checkpoints", "ckpnt-30000")
+    nodes = tf_graph.load_meta_graph(prefix + ".meta")
+    gi = tf_graph.GraphInterpreter(nodes, checkpoint.read_checkpoint(prefix), np.float64)
+    x = graph_golden["x"][:12]
+    p = gi.run("accuracy/Sigmoid", {"data/Placeholder": x.reshape(-1, 35, 1), "dropout": np.float32(1.0)})
+    assert np.array_equal(np.asarray(p).reshape(-1), graph_golden["ckpt_f64_probs"][:12 * 35])
+    # dropout wiring: keep_prob < 1 must change the result (the cells are wrapped, rnn_class.py:152)
+    gi2 = tf_graph.GraphInterpreter(nodes, checkpoint.read_checkpoint(prefix), np.float64, seed=1)
+    q = gi2.run("accuracy/Sigmoid", {"data/Placeholder": x.reshape(-1, 35, 1), "dropout": np.float32(0.8)})
+    assert np.abs(np.asarray(q).reshape(-1) - np.asarray(p).reshape(-1)).max() > 1e-4
