@@ -273,7 +273,7 @@ def read_checkpoint(prefix: str, names: Iterable[str] = None, verify_crc: bool =
 def is_inference_tensor(name: str) -> bool:
     """True for the 74 tensors the forward pass needs (optimizer slots skipped)."""
     return "RMSProp" not in name and "Adam" not in name and \
-        name not in ("beta1_power", "beta2_power")
+        not name.endswith(("beta1_power", "beta2_power"))
 
 
 def read_inference_weights(path: str, ckpnt: str = "latest") -> "OrderedDict[str, np.ndarray]":
@@ -281,6 +281,15 @@ def read_inference_weights(path: str, ckpnt: str = "latest") -> "OrderedDict[str
     entries = read_index(prefix + ".index")
     names = [n for n in entries if is_inference_tensor(n)]
     return read_checkpoint(prefix, names)
+
+
+def read_optimizer_state(path: str, ckpnt: str = "latest") -> "OrderedDict[str, np.ndarray]":
+    """The non-inference entries of a bundle: optimizer slot variables (``<var>/RMSProp``, ``<var>/RMSProp_1``,
+    ``<var>/Adam``, ``<var>/Adam_1``, ``.../beta{1,2}_power``) as tf.train.Saver stored them."""
+    prefix = _resolve_prefix(path, ckpnt)
+    entries = read_index(prefix + ".index")
+    names = [n for n in entries if not is_inference_tensor(n)]
+    return read_checkpoint(prefix, names) if names else OrderedDict()
 
 
 # --------------------------------------------------------------------------- writer

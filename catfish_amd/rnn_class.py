@@ -80,6 +80,7 @@ class RNN(object):
         if self.engine is not None:
             self.engine.close()
         self.weights = weights
+        self.optimizer_state = None
         self._trainer = None
         self._engine_stale = False
         self.engine = HipEngine(weights, layer_size=self.layer_size, n_layers=self.n_layers,
@@ -135,6 +136,8 @@ class RNN(object):
         """rnn_class.py:191-198: load checkpoint ``path/ckpnt`` (or the latest one in ``path``)."""
         weights = checkpoint.read_inference_weights(path, ckpnt)
         self._load_engine(weights)
+        # saver.restore also brings the optimizer slots back; train_network continues from them
+        self.optimizer_state = checkpoint.read_optimizer_state(path, ckpnt)
         parts = path.split("/")
         print("Model {} restored\n".format(parts[-2] if len(parts) >= 2 else path))
 
@@ -198,7 +201,8 @@ class RNN(object):
         if self._trainer is None:
             from .training import Trainer
             self._trainer = Trainer(self.weights, self.n_layers, self.n_layers_res_, self.optimizer_choice,
-                                    self.learning_rate, self.keep_prob, seed=self.train_seed)
+                                    self.learning_rate, self.keep_prob, seed=self.train_seed,
+                                    optimizer_state=getattr(self, "optimizer_state", None))
         self.train_loss = self._trainer.train_step(train_x, train_y)
         self._engine_stale = True
 
@@ -206,12 +210,17 @@ class RNN(object):
         """Write the current weights as a TensorFlow checkpoint-V2 bundle ``path/ckpnt-<step>`` that the
         original tool's ``restore_network`` (rnn_class.py:191-198) and this one can both read
         (the reference saves with ``saver.save(sess, ".../checkpoints/ckpnt", global_step=step)``,
-        networks/train_validate.py:154-155).  Optimizer slots are not written."""
+        networks/train_validate.py:154-155).  Like tf.train.Saver it stores the optimizer slot variables
+        (``<var>/RMSProp`` ... ) next to the weights once a training step has run."""
         if self.weights is None:
             raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
         weights = self._trainer.net.numpy_weights() if self._trainer is not None else self.weights
         prefix = os.path.join(path, "ckpnt-%d" % int(step))
-        checkpoint.write_checkpoint(prefix, {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()})
+        tensors = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        state = self._trainer.opt.state_tf() if self._trainer is not None else getattr(self, "optimizer_state", None)
+        for k, v in (state or {}).items():
+            tensors[k] = np.asarray(v, dtype=np.float32)
+        checkpoint.write_checkpoint(prefix, tensors)
         with open(os.path.join(path, "checkpoint"), "w") as fh:
             fh.write('model_checkpoint_path: "ckpnt-%d"\nall_model_checkpoint_paths: "ckpnt-%d"\n' % (int(step), int(step)))
         return prefix

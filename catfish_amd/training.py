@@ -144,6 +144,41 @@ class TFOptimizer(object):
             self.ms = {k: torch.ones_like(v) for k, v in params.items()}      # TF initialises the rms slot to 1
             self.mom = {k: torch.zeros_like(v) for k, v in params.items()}
 
+    # ---- slot variables under their TensorFlow names (what tf.train.Saver writes next to the weights) ----------
+    def state_tf(self):
+        """{checkpoint name: ndarray}: ``<var>/RMSProp`` (rms), ``<var>/RMSProp_1`` (momentum) or ``<var>/Adam`` (m),
+        ``<var>/Adam_1`` (v), ``optimizer/beta{1,2}_power`` (the optimizer is built under name_scope "optimizer",
+        rnn_class.py:62-71)."""
+        out = {}
+        if self.choice == "Adam":
+            t = float(self.t)
+            for k in self.params:
+                out[k + "/Adam"] = self.m[k].detach().cpu().numpy().astype(np.float32)
+                out[k + "/Adam_1"] = self.v[k].detach().cpu().numpy().astype(np.float32)
+            out["optimizer/beta1_power"] = np.float32(0.9 ** (t + 1))       # TF stores beta^(t+1): initial value beta
+            out["optimizer/beta2_power"] = np.float32(0.999 ** (t + 1))
+        else:
+            for k in self.params:
+                out[k + "/RMSProp"] = self.ms[k].detach().cpu().numpy().astype(np.float32)
+                out[k + "/RMSProp_1"] = self.mom[k].detach().cpu().numpy().astype(np.float32)
+        return out
+
+    def load_state_tf(self, state):
+        """Continue from restored slot variables (``saver.restore`` brings them back, rnn_class.py:191-198).
+        Entries of the other optimizer, or missing ones, leave the fresh initial value in place."""
+        torch = self.torch
+        a, b = ("Adam", "Adam_1") if self.choice == "Adam" else ("RMSProp", "RMSProp_1")
+        first, second = (self.m, self.v) if self.choice == "Adam" else (self.ms, self.mom)
+        with torch.no_grad():
+            for k, p in self.params.items():
+                for slot, name in ((first, k + "/" + a), (second, k + "/" + b)):
+                    if name in state:
+                        slot[k].copy_(torch.as_tensor(np.asarray(state[name]), dtype=p.dtype).reshape(p.shape))
+            if self.choice == "Adam":
+                for name in ("optimizer/beta1_power", "beta1_power"):
+                    if name in state and 0.0 < float(state[name]) < 1.0:
+                        self.t.fill_(round(np.log(float(state[name])) / np.log(0.9)) - 1)
+
     def step(self):
         """One update of every parameter with multi-tensor (``torch._foreach_*``) ops: a handful of launches
         instead of ~8 per parameter tensor (66 tensors)."""
@@ -174,9 +209,10 @@ class TFOptimizer(object):
                 torch._foreach_addcmul_(rms, gs, gs, value=1 - decay)
                 den = torch._foreach_add(rms, eps)
                 torch._foreach_sqrt_(den)
-                upd = torch._foreach_div(gs, den)                  # momentum = 0
+                upd = torch._foreach_div(gs, den)                  # momentum = 0: mom = lr * g / sqrt(ms + eps)
                 torch._foreach_mul_(upd, self.lr)
                 torch._foreach_sub_(ps, upd)
+                torch._foreach_copy_([self.mom[k] for k in keys], upd)
             if not self.keep_grads:
                 for p in ps:
                     p.grad = None
@@ -191,12 +227,14 @@ class Trainer(object):
     """
 
     def __init__(self, weights, n_layers, n_layers_res, optimizer_choice, learning_rate, keep_prob, device=None,
-                 seed=None, use_graph=None, native=None):
+                 seed=None, use_graph=None, native=None, optimizer_state=None, dtype=None):
         import torch
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
-        self.net = TorchResNetRNN(weights, n_layers, n_layers_res, device=device)
+        self.net = TorchResNetRNN(weights, n_layers, n_layers_res, device=device, dtype=dtype)
         self.opt = TFOptimizer(self.net.trainable(), optimizer_choice, learning_rate)
+        if optimizer_state:
+            self.opt.load_state_tf(optimizer_state)
         self.keep_prob = float(keep_prob)
         self.gen = torch.Generator(device=self.net.device)
         if seed is not None:

@@ -257,20 +257,54 @@ class GraphInterpreter(object):
                         self.merge_frame[n.name] = fr
                         self.frame_merges.setdefault(fr, []).append(n.name)
         self.frame_cond = {}
+        self.exit_merge = {}
+        self.frame_exits = {}
         for n in nodes.values():
-            if n.op == "Switch" and n.inputs[0][0] in self.merge_frame:
-                self.frame_cond[self.merge_frame[n.inputs[0][0]]] = n.inputs[1]
+            if n.op == "Switch":
+                m = self._through_identity(n.inputs[0][0])
+                if m in self.merge_frame:
+                    self.frame_cond[self.merge_frame[m]] = n.inputs[1]
+            elif n.op == "Exit":
+                sw = self._through_identity(n.inputs[0][0])
+                if nodes[sw].op == "Switch":
+                    m = self._through_identity(nodes[sw].inputs[0][0])
+                    if m in self.merge_frame:
+                        self.exit_merge[n.name] = m
+                        self.frame_exits.setdefault(self.merge_frame[m], []).append(n.name)
+        # gradient stacks: the pushes sit in the forward loop and nothing in that loop consumes them
+        self.frame_pushes = {}
+        for n in nodes.values():
+            if n.op == "StackPushV2" and nodes[n.inputs[0][0]].op == "Enter":
+                self.frame_pushes.setdefault(nodes[n.inputs[0][0]].attr["frame_name"], []).append(n.name)
+        self.grad_arrays = {}
+        self.updates = {}
+
+    def _through_identity(self, name):
+        while self.nodes[name].op == "Identity":
+            name = self.nodes[name].inputs[0][0]
+        return name
 
     def _f(self, arr):
         arr = np.asarray(arr)
         return arr.astype(self.fdt) if arr.dtype.kind == "f" else arr
 
-    def run(self, fetch: str, feeds: Dict[str, np.ndarray]):
+    def run(self, fetch, feeds: Dict[str, np.ndarray]):
+        """fetch: a tensor name ("node" or "node:k") or a list of them (evaluated in ONE pass, like one
+        session.run: loops, stacks and random ops execute once)."""
+        import sys
+        if sys.getrecursionlimit() < 50000:
+            sys.setrecursionlimit(50000)
         ctx = _Ctx()
         for k, v in feeds.items():
             ctx.memo[(k, 0)] = self._f(v)
-        name, idx = (fetch.rsplit(":", 1) + ["0"])[:2] if ":" in fetch else (fetch, "0")
-        return self.eval((name, int(idx)), ctx)
+        self.grad_arrays = {}
+        self.updates = {}
+        many = isinstance(fetch, (list, tuple))
+        out = []
+        for f in (fetch if many else [fetch]):
+            name, idx = f.rsplit(":", 1) if ":" in f else (f, "0")
+            out.append(self.eval((name, int(idx)), ctx))
+        return out if many else out[0]
 
     # -- evaluation ------------------------------------------------------------------------
     def eval(self, tensor, ctx):
@@ -295,7 +329,7 @@ class GraphInterpreter(object):
                 return ctx.merges[name]
             raise RuntimeError("Merge %s evaluated outside its loop" % name)
         if op == "Exit":
-            self._run_loop(self.merge_frame[self.nodes[node.inputs[0][0]].inputs[0][0]], ctx)
+            self._run_loop(self.merge_frame[self.exit_merge[name]], ctx)
             return ctx.memo[tensor]
         if op == "NextIteration":
             raise RuntimeError("NextIteration reached directly: %s" % name)
@@ -320,15 +354,14 @@ class GraphInterpreter(object):
             it = _Ctx(outer=ctx, merges=values)
             if not bool(self.eval(self.frame_cond[frame], it)):
                 break
+            for push in self.frame_pushes.get(frame, ()):
+                self.eval((push, 0), it)
             values = {m: self.eval(nexts[m], it) for m in merges}
             guard += 1
             if guard > 100000:
                 raise RuntimeError("while loop %s does not terminate" % frame)
-        for n in self.nodes.values():
-            if n.op == "Exit":
-                sw = self.nodes[n.inputs[0][0]]
-                if sw.op == "Switch" and self.merge_frame.get(sw.inputs[0][0]) == frame:
-                    ctx.memo[(n.name, 0)] = values[sw.inputs[0][0]]
+        for ex in self.frame_exits.get(frame, ()):
+            ctx.memo[(ex, 0)] = values[self.exit_merge[ex]]
 
     # -- op kernels (TF-1.10 op definitions) -------------------------------------------------
     def _kernel(self, node, a):
@@ -427,8 +460,72 @@ class GraphInterpreter(object):
             if not axes and np.ndim(a[1]) == 1:             # empty reduction_indices: nothing is reduced
                 return [np.asarray(a[0])]
             return [fn(a[0], axis=axes, keepdims=bool(at.get("keep_dims")), dtype=np.asarray(a[0]).dtype)]
-        if op == "NoOp":
+        if op in ("NoOp", "ControlTrigger"):
             return [None]
+        # ---- gradient graph -------------------------------------------------------------------
+        if op == "StackV2":
+            return [[]]
+        if op == "StackPushV2":
+            a[0].append(a[1])
+            return [a[1]]
+        if op == "StackPopV2":
+            return [a[0].pop()]
+        if op == "TensorArrayGradV3":                      # one gradient array per (forward array, source)
+            key = (id(a[0]), at["source"])
+            if key not in self.grad_arrays:
+                self.grad_arrays[key] = _TensorArray(len(a[0].items))
+                self.grad_arrays[key].is_grad = True
+            return [self.grad_arrays[key], np.float32(0)]
+        if op == "AddN":
+            out = a[0]
+            for v in a[1:]:
+                out = out + v
+            return [out]
+        if op == "Reciprocal":
+            return [1.0 / a[0]]
+        if op == "FloorMod":
+            return [np.mod(a[0], a[1])]
+        if op == "InvertPermutation":
+            return [np.argsort(np.asarray(a[0])).astype(np.asarray(a[0]).dtype)]
+        if op == "ShapeN":
+            return [np.array(np.shape(v), dtype=np.int32) for v in a]
+        if op == "ConcatOffset":                            # offsets of each input along concat_dim
+            dim = int(a[0])
+            outs, off = [], 0
+            for shp in a[1:]:
+                o = np.zeros(len(shp), dtype=np.int32)
+                o[dim] = off
+                off += int(shp[dim])
+                outs.append(o)
+            return outs
+        if op == "Slice":
+            idx = tuple(slice(int(b), None if int(sz) == -1 else int(b) + int(sz)) for b, sz in zip(a[1], a[2]))
+            return [np.asarray(a[0])[idx]]
+        if op == "Tile":
+            return [np.tile(a[0], [int(v) for v in a[1]])]
+        if op == "BroadcastGradientArgs":
+            return list(self._broadcast_gradient_args(a[0], a[1]))
+        if op == "BiasAddGrad":
+            g = np.asarray(a[0])
+            return [g.reshape(-1, g.shape[-1]).sum(axis=0)]
+        if op == "ReluGrad":
+            return [a[0] * (a[1] > 0)]
+        if op == "TanhGrad":                                # (y, dy)
+            return [a[1] * (1.0 - a[0] * a[0])]
+        if op == "SigmoidGrad":                             # (y, dy)
+            return [a[1] * a[0] * (1.0 - a[0])]
+        if op == "Conv2DBackpropInput":
+            return [self._conv2d_backprop_input([int(v) for v in a[0]], a[1], a[2], at)]
+        if op == "Conv2DBackpropFilter":
+            return [self._conv2d_backprop_filter(a[0], [int(v) for v in a[1]], a[2], at)]
+        if op == "ApplyRMSProp":                            # training_ops.cc: ms, mom, var in that order
+            var, ms, mom, lr, rho, momentum, eps, g = a
+            ms_new = ms + (g * g - ms) * (1.0 - rho)
+            mom_new = mom * momentum + lr * g / np.sqrt(ms_new + eps)
+            var_new = var - mom_new
+            for src, val in zip(node.inputs[:3], (var_new, ms_new, mom_new)):
+                self.updates[src[0]] = val
+            return [var_new]
         if op == "Max":
             return [np.max(a[0], axis=tuple(int(v) for v in np.atleast_1d(a[1])), keepdims=bool(at.get("keep_dims")))]
         if op == "StridedSlice":
@@ -445,7 +542,11 @@ class GraphInterpreter(object):
         if op == "TensorArrayReadV3":
             return [a[0].items[int(a[1])]]
         if op == "TensorArrayWriteV3":
-            a[0].items[int(a[1])] = a[2]
+            i = int(a[1])
+            if getattr(a[0], "is_grad", False) and a[0].items[i] is not None:
+                a[0].items[i] = a[0].items[i] + a[2]        # gradient arrays aggregate repeated writes
+            else:
+                a[0].items[i] = a[2]
             return [np.float32(0)]
         if op == "TensorArrayGatherV3":
             return [np.stack([a[0].items[i] for i in np.asarray(a[1]).tolist()])]
@@ -475,6 +576,47 @@ class GraphInterpreter(object):
             for j in range(kw):
                 out += xp[:, i:i + oh, j:j + ow, :] @ w[i, j]
         return out
+
+    @staticmethod
+    def _same_geometry(x_shape, w_shape, at):
+        assert at.get("data_format", "NHWC") == "NHWC" and list(at.get("strides", [1, 1, 1, 1])) == [1, 1, 1, 1], at
+        assert at["padding"] == "SAME", at
+        kh, kw = w_shape[0], w_shape[1]
+        return kh, kw, (kh - 1) // 2, (kw - 1) // 2
+
+    @classmethod
+    def _conv2d_backprop_input(cls, x_shape, w, dy, at):
+        """dx[n,h,w,:] = sum_{i,j} dy[n,h-i+pt,w-j+pl,:] @ w[i,j]^T  (transpose of _conv2d)."""
+        kh, kw, pt, pl = cls._same_geometry(x_shape, w.shape, at)
+        n, h, wd, _ = x_shape
+        dxp = np.zeros((n, h + kh - 1, wd + kw - 1, w.shape[2]), dtype=np.result_type(dy, w))
+        for i in range(kh):
+            for j in range(kw):
+                dxp[:, i:i + h, j:j + wd, :] += dy @ w[i, j].T
+        return dxp[:, pt:pt + h, pl:pl + wd, :]
+
+    @classmethod
+    def _conv2d_backprop_filter(cls, x, w_shape, dy, at):
+        """dw[i,j] = sum_{n,h,w} x[n,h+i-pt,w+j-pl,:]^T dy[n,h,w,:]."""
+        kh, kw, pt, pl = cls._same_geometry(x.shape, w_shape, at)
+        n, h, wd, cin = x.shape
+        xp = np.pad(x, ((0, 0), (pt, kh - 1 - pt), (pl, kw - 1 - pl), (0, 0)))
+        dw = np.zeros(w_shape, dtype=np.result_type(x, dy))
+        d2 = dy.reshape(-1, dy.shape[-1])
+        for i in range(kh):
+            for j in range(kw):
+                dw[i, j] = xp[:, i:i + h, j:j + wd, :].reshape(-1, cin).T @ d2
+        return dw
+
+    @staticmethod
+    def _broadcast_gradient_args(s0, s1):
+        """Reduction axes that undo numpy-style broadcasting of shapes s0 and s1 (ops/array_ops.cc)."""
+        s0, s1 = [int(v) for v in s0], [int(v) for v in s1]
+        rank = max(len(s0), len(s1))
+        p0, p1 = [1] * (rank - len(s0)) + s0, [1] * (rank - len(s1)) + s1
+        r0 = [d for d in range(rank) if p0[d] == 1 and (p1[d] != 1 or d < rank - len(s0))]
+        r1 = [d for d in range(rank) if p1[d] == 1 and (p0[d] != 1 or d < rank - len(s1))]
+        return np.array(r0, dtype=np.int32), np.array(r1, dtype=np.int32)
 
     @staticmethod
     def _strided_slice(x, begin, end, strides, at):

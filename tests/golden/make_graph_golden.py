@@ -8,7 +8,8 @@ evaluates its inference subgraph ``data/Placeholder -> accuracy/Sigmoid`` (rnn_c
 with the variables of ``ckpnt-30000`` and with a seeded random weight set.
 
 Run in the build container (needs /root/reference):   python tests/golden/make_graph_golden.py
-Writes tests/golden/graph_golden.npz and tests/golden/graph_summary.json.
+Writes tests/golden/graph_golden.npz, tests/golden/graph_train_golden.npz (three optimizer steps of the
+reference's gradient + ApplyRMSProp subgraph, rnn_class.py:62-71,201-210) and tests/golden/graph_summary.json.
 """
 import json
 import os
@@ -60,6 +61,44 @@ def run(nodes, variables, x, y, dtype):
     return out, gi.ops_used
 
 
+TRAIN_STEPS = 3
+TRAIN_BATCH = 16
+
+
+def train_trajectory(nodes, variables):
+    """TRAIN_STEPS session.run(optimizer) calls of the reference graph (rnn_class.py:201-210) in exact arithmetic:
+    loss -> optimizer/gradients/* -> ApplyRMSProp, from the checkpoint's weights with FRESH slot variables
+    (rms = 1, momentum = 0: the optimizer's own initial values), dropout keep_prob = 1."""
+    rng = np.random.RandomState(20260102)
+    xs = (rng.randn(TRAIN_STEPS, TRAIN_BATCH, 35) * 1.5).astype(np.float32)
+    ys = (rng.rand(TRAIN_STEPS, TRAIN_BATCH, 35) < 0.3).astype(np.float32)
+    state = {k: np.asarray(v, dtype=np.float64) for k, v in variables.items()}
+    for k in state:
+        if k.endswith("/RMSProp"):
+            state[k] = np.ones_like(state[k])
+        elif k.endswith("/RMSProp_1"):
+            state[k] = np.zeros_like(state[k])
+    start = {k: v.copy() for k, v in state.items()}
+    applies = sorted(k for k, n in nodes.items() if n.op == "ApplyRMSProp")
+    grad_of = {nodes[a].inputs[0][0]: "%s:%d" % nodes[a].inputs[7] for a in applies}
+    out = {"train_x": xs, "train_y": ys, "train_loss": np.zeros(TRAIN_STEPS)}
+    for step in range(TRAIN_STEPS):
+        gi = G.GraphInterpreter(nodes, state, np.float64)
+        names = sorted(grad_of)
+        res = gi.run(["loss/Mean"] + [grad_of[k] for k in names] + applies,
+                     {"data/Placeholder": xs[step].reshape(-1, 35, 1), "data/Placeholder_1": ys[step].reshape(-1, 35, 1),
+                      "dropout": np.float32(1.0)})
+        out["train_loss"][step] = float(res[0])
+        if step == 0:
+            for k, g in zip(names, res[1:1 + len(names)]):
+                out["train_grad0/" + k] = np.asarray(g).reshape(state[k].shape).astype(np.float32)
+        assert len(gi.updates) == 3 * len(applies)
+        state.update(gi.updates)
+    for k in sorted(grad_of):
+        out["train_delta/" + k] = (state[k] - start[k]).astype(np.float32)
+    return out
+
+
 def summary(nodes):
     sub = G.inference_subgraph(nodes, FETCH)
     ops = {}
@@ -104,6 +143,9 @@ def main():
     arrays["rand_f64_loss"] = out["loss"]
     arrays["random_seed"] = np.int64(RANDOM_SEED)
     np.savez_compressed(os.path.join(HERE, "graph_golden.npz"), **arrays)
+    train = train_trajectory(nodes, variables)
+    np.savez_compressed(os.path.join(HERE, "graph_train_golden.npz"), **train)
+    print("train losses", train["train_loss"])
     sm = summary(nodes)
     sm["ops_executed"] = dict(sorted(used.items()))
     with open(os.path.join(HERE, "graph_summary.json"), "w") as fh:

@@ -251,19 +251,21 @@ def test_streaming_pipeline_matches_oracle(model, ckpt_weights):
         pipe.submit([np.zeros(20000, np.int16)])
 
 
-def test_native_gru_training_kernels_match_torch_autograd():
+@pytest.mark.parametrize("n", [40, 2100])
+def test_native_gru_training_kernels_match_torch_autograd(n):
     """cf_gru_train_forward/backward (+ library GEMMs for dW) against torch autograd of the restated graph:
-    same loss, same gradients for every parameter and for the input."""
+    same loss, same gradients for every parameter and for the input.  40 windows run the four-waves-per-tile
+    (latency) kernels, 2100 windows (2 x 132 tiles > 256 CUs) the one-wave-per-tile (throughput) kernels."""
     torch = pytest.importorskip("torch")
     from catfish_amd.training import TorchResNetRNN
     from catfish_amd.engine import HipEngine
     w = oracle.random_weights(seed=31)
     rng = np.random.default_rng(2)
-    x = rng.normal(0, 1.2, size=(40, 35)).astype(np.float32)          # not a multiple of 16: exercises the padding
-    y = np.repeat((np.arange(40) % 2)[:, None], 35, axis=1).astype(np.float32)
+    x = rng.normal(0, 1.2, size=(n, 35)).astype(np.float32)           # not a multiple of 16: exercises the padding
+    y = np.repeat((np.arange(n) % 2)[:, None], 35, axis=1).astype(np.float32)
     ref = TorchResNetRNN(w, 3, 2, device="cuda")
     nat = TorchResNetRNN(w, 3, 2, device="cuda")
-    eng = HipEngine(w, device=0, max_windows_per_pass=256, fuse_layers=False)
+    eng = HipEngine(w, device=0, max_windows_per_pass=max(256, n), fuse_layers=False)
     try:
         l_ref = ref.loss(x, y)
         l_ref.backward()
@@ -296,6 +298,28 @@ def test_native_trainer_follows_the_torch_trainer():
     assert np.allclose(la, lb, rtol=0, atol=2e-4), (la, lb)
     assert la[-1] < la[0]
     a.engine.close()
+
+
+def test_native_trainer_follows_the_reference_training_graph(ckpt_weights):
+    """Three RMSProp steps on the HIP training kernels (fp32, graph-captured) against the same three steps of the
+    reference's own TF graph interpreted in fp64 (tests/golden/graph_train_golden.npz from make_graph_golden.py):
+    per-step loss and the accumulated change of all 58 trainable variables."""
+    import os
+    pytest.importorskip("torch")
+    from catfish_amd.training import Trainer
+    from conftest import GOLDEN
+    with np.load(os.path.join(GOLDEN, "graph_train_golden.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    tr = Trainer(ckpt_weights, 3, 2, "RMSProp", 1e-3, keep_prob=1.0, device="cuda", native=True)
+    start = {k: v.detach().clone() for k, v in tr.net.trainable().items()}
+    for step in range(g["train_x"].shape[0]):
+        loss = tr.train_step(g["train_x"][step], g["train_y"][step])
+        assert abs(loss - float(g["train_loss"][step])) < 5e-6, (step, loss)
+    for k, p in tr.net.trainable().items():
+        delta = (p.detach() - start[k]).cpu().numpy()
+        ref = g["train_delta/" + k]
+        assert np.abs(delta - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-8, (k, np.abs(delta - ref).max(), np.abs(ref).max())
+    tr.engine.close()
 
 
 def test_cli_end_to_end(tmp_path, ckpt_weights, monkeypatch):

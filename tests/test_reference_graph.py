@@ -98,3 +98,78 @@ def test_golden_regenerates_from_the_reference_meta_graph(graph_golden):
     gi2 = tf_graph.GraphInterpreter(nodes, checkpoint.read_checkpoint(prefix), np.float64, seed=1)
     q = gi2.run("accuracy/Sigmoid", {"data/Placeholder": x.reshape(-1, 35, 1), "dropout": np.float32(0.8)})
     assert np.abs(np.asarray(q).reshape(-1) - np.asarray(p).reshape(-1)).max() > 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# The training step (rnn_class.py:62-71, 201-210): the reference's gradient + ApplyRMSProp subgraph
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def train_golden():
+    with np.load(os.path.join(GOLDEN, "graph_train_golden.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _close(a, b, rtol):
+    return np.abs(a - b).max() <= rtol * np.abs(b).max() + 1e-12
+
+
+def test_training_trajectory_matches_reference_graph(ckpt_weights, train_golden):
+    """Three optimizer steps of the reference's own graph (loss -> optimizer/gradients/* -> ApplyRMSProp,
+    interpreted in fp64) vs catfish_amd.training in fp64: losses, first-step gradients of all 58 trainable
+    variables, and the accumulated weight change."""
+    import torch
+    from catfish_amd.training import Trainer
+    tr = Trainer(ckpt_weights, 3, 2, "RMSProp", 1e-3, 1.0, device="cpu", use_graph=False, native=False, dtype=torch.float64)
+    xs, ys = train_golden["train_x"], train_golden["train_y"]
+    start = {k: v.detach().clone() for k, v in tr.net.trainable().items()}
+    assert len(start) == 58
+    # first-step gradients
+    loss = tr.net.loss(torch.from_numpy(xs[0]).double(), torch.from_numpy(ys[0]).double())
+    loss.backward()
+    for k, p in tr.net.trainable().items():
+        assert _close(p.grad.numpy(), train_golden["train_grad0/" + k], 1e-6), k
+        p.grad = None
+    for step in range(xs.shape[0]):
+        got = tr.train_step(xs[step], ys[step])
+        assert abs(got - float(train_golden["train_loss"][step])) < 1e-9, step
+    for k, p in tr.net.trainable().items():
+        delta = (p.detach() - start[k]).numpy()
+        assert _close(delta, train_golden["train_delta/" + k], 1e-6), k
+
+
+@pytest.mark.skipif(not has_reference(), reason="needs /root/reference (build container only)")
+def test_restore_then_train_continues_from_the_saved_slots(tmp_path):
+    """saver.restore brings the RMSProp slots back (rnn_class.py:191-198); one step from ckpnt-30000's own slot
+    variables, reference graph vs TFOptimizer.load_state_tf, and the slots survive a save/restore round trip."""
+    import torch
+    from catfish_amd import checkpoint
+    from catfish_amd.training import Trainer
+    from oracle import tf_graph
+    path = os.path.join(REFERENCE, "catfish", "ResNetRNN", "checkpoints")
+    variables = checkpoint.read_checkpoint(os.path.join(path, "ckpnt-30000"))
+    state = checkpoint.read_optimizer_state(path, "ckpnt-30000")
+    weights = checkpoint.read_inference_weights(path, "ckpnt-30000")
+    assert len(state) == 116 and len(weights) == 74
+    nodes = tf_graph.load_meta_graph(os.path.join(path, "ckpnt-30000.meta"))
+    rng = np.random.RandomState(5)
+    x = (rng.randn(8, 35) * 1.5).astype(np.float32)
+    y = (rng.rand(8, 35) < 0.3).astype(np.float32)
+    gi = tf_graph.GraphInterpreter(nodes, variables, np.float64)
+    applies = sorted(k for k, n in nodes.items() if n.op == "ApplyRMSProp")
+    gi.run(applies, {"data/Placeholder": x.reshape(-1, 35, 1), "data/Placeholder_1": y.reshape(-1, 35, 1), "dropout": np.float32(1.0)})
+    tr = Trainer(weights, 3, 2, "RMSProp", 1e-3, 1.0, device="cpu", use_graph=False, native=False, dtype=torch.float64,
+                 optimizer_state=state)
+    tr.train_step(x, y)
+    for k, p in tr.net.trainable().items():
+        ref_delta = gi.updates[k] - variables[k].astype(np.float64)
+        # 1e-6: the graph's constants are float32 (lr 0.0010000000475, decay 0.89999998), the trainer's are doubles
+        assert _close(p.detach().numpy() - variables[k].astype(np.float64), ref_delta, 1e-6), k
+        assert _close(tr.opt.ms[k].numpy(), gi.updates[k + "/RMSProp"], 1e-6), k
+        assert _close(tr.opt.mom[k].numpy(), gi.updates[k + "/RMSProp_1"], 1e-6), k
+    # the slots travel through save_network's bundle
+    tensors = dict(tr.net.numpy_weights())
+    tensors.update(tr.opt.state_tf())
+    checkpoint.write_checkpoint(str(tmp_path / "ckpnt-1"), tensors)
+    back = checkpoint.read_optimizer_state(str(tmp_path), "ckpnt-1")
+    assert set(back) == set(state)
+    assert np.array_equal(back["conv1d/kernel/RMSProp"], tr.opt.ms["conv1d/kernel"].numpy().astype(np.float32))
