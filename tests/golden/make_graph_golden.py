@@ -65,10 +65,14 @@ TRAIN_STEPS = 3
 TRAIN_BATCH = 16
 
 
-def train_trajectory(nodes, variables):
+def train_trajectory(nodes, variables, store32=False, tag="train"):
     """TRAIN_STEPS session.run(optimizer) calls of the reference graph (rnn_class.py:201-210) in exact arithmetic:
     loss -> optimizer/gradients/* -> ApplyRMSProp, from the checkpoint's weights with FRESH slot variables
-    (rms = 1, momentum = 0: the optimizer's own initial values), dropout keep_prob = 1."""
+    (rms = 1, momentum = 0: the optimizer's own initial values), dropout keep_prob = 1.
+
+    store32: round every assigned variable to float32 between steps, as TF's float32 variables do (the arithmetic
+    of each step stays exact).  A float32 trainer follows THAT trajectory; the exact one is for float64 runs: the
+    one-ulp storage rounding of step k moves the gradients of step k+1 by up to ~1 %."""
     rng = np.random.RandomState(20260102)
     xs = (rng.randn(TRAIN_STEPS, TRAIN_BATCH, 35) * 1.5).astype(np.float32)
     ys = (rng.rand(TRAIN_STEPS, TRAIN_BATCH, 35) < 0.3).astype(np.float32)
@@ -81,21 +85,24 @@ def train_trajectory(nodes, variables):
     start = {k: v.copy() for k, v in state.items()}
     applies = sorted(k for k, n in nodes.items() if n.op == "ApplyRMSProp")
     grad_of = {nodes[a].inputs[0][0]: "%s:%d" % nodes[a].inputs[7] for a in applies}
-    out = {"train_x": xs, "train_y": ys, "train_loss": np.zeros(TRAIN_STEPS)}
+    out = {"train_x": xs, "train_y": ys, tag + "_loss": np.zeros(TRAIN_STEPS)}
     for step in range(TRAIN_STEPS):
         gi = G.GraphInterpreter(nodes, state, np.float64)
         names = sorted(grad_of)
         res = gi.run(["loss/Mean"] + [grad_of[k] for k in names] + applies,
                      {"data/Placeholder": xs[step].reshape(-1, 35, 1), "data/Placeholder_1": ys[step].reshape(-1, 35, 1),
                       "dropout": np.float32(1.0)})
-        out["train_loss"][step] = float(res[0])
-        if step == 0:
+        out[tag + "_loss"][step] = float(res[0])
+        if step == 0 and not store32:
             for k, g in zip(names, res[1:1 + len(names)]):
                 out["train_grad0/" + k] = np.asarray(g).reshape(state[k].shape).astype(np.float32)
         assert len(gi.updates) == 3 * len(applies)
-        state.update(gi.updates)
+        if store32:
+            state.update({k: v.astype(np.float32).astype(np.float64) for k, v in gi.updates.items()})
+        else:
+            state.update(gi.updates)
     for k in sorted(grad_of):
-        out["train_delta/" + k] = (state[k] - start[k]).astype(np.float32)
+        out[tag + "_delta/" + k] = (state[k] - start[k]).astype(np.float32)
     return out
 
 
@@ -144,6 +151,7 @@ def main():
     arrays["random_seed"] = np.int64(RANDOM_SEED)
     np.savez_compressed(os.path.join(HERE, "graph_golden.npz"), **arrays)
     train = train_trajectory(nodes, variables)
+    train.update(train_trajectory(nodes, variables, store32=True, tag="train32"))
     np.savez_compressed(os.path.join(HERE, "graph_train_golden.npz"), **train)
     print("train losses", train["train_loss"])
     sm = summary(nodes)

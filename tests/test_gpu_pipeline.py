@@ -302,8 +302,9 @@ def test_native_trainer_follows_the_torch_trainer():
 
 def test_native_trainer_follows_the_reference_training_graph(ckpt_weights):
     """Three RMSProp steps on the HIP training kernels (fp32, graph-captured) against the same three steps of the
-    reference's own TF graph interpreted in fp64 (tests/golden/graph_train_golden.npz from make_graph_golden.py):
-    per-step loss and the accumulated change of all 58 trainable variables."""
+    reference's own TF graph (tests/golden/graph_train_golden.npz from make_graph_golden.py; exact arithmetic per
+    step, variables stored as float32 between steps like TF's): per-step loss and the accumulated change of all 58
+    trainable variables."""
     import os
     pytest.importorskip("torch")
     from catfish_amd.training import Trainer
@@ -314,11 +315,13 @@ def test_native_trainer_follows_the_reference_training_graph(ckpt_weights):
     start = {k: v.detach().clone() for k, v in tr.net.trainable().items()}
     for step in range(g["train_x"].shape[0]):
         loss = tr.train_step(g["train_x"][step], g["train_y"][step])
-        assert abs(loss - float(g["train_loss"][step])) < 5e-6, (step, loss)
+        assert abs(loss - float(g["train32_loss"][step])) < 5e-6, (step, loss)
     for k, p in tr.net.trainable().items():
         delta = (p.detach() - start[k]).cpu().numpy()
-        ref = g["train_delta/" + k]
-        assert np.abs(delta - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-8, (k, np.abs(delta - ref).max(), np.abs(ref).max())
+        ref = g["train32_delta/" + k]
+        # an update that lands near a rounding boundary may round the other way: one ulp(|p|) per step
+        slack = 3e-3 * np.abs(ref).max() + 3 * np.finfo(np.float32).eps * float(start[k].abs().max()) + 1e-8
+        assert np.abs(delta - ref).max() <= slack, (k, np.abs(delta - ref).max(), np.abs(ref).max())
     tr.engine.close()
 
 
