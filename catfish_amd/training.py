@@ -56,11 +56,12 @@ class TorchResNetRNN(object):
         inv = p[bn(j) + "/gamma"] * torch.rsqrt(p[bn(j) + "/moving_variance"] + 1e-3)
         return y * inv[None, :, None] + (p[bn(j) + "/beta"] - p[bn(j) + "/moving_mean"] * inv)[None, :, None]
 
-    def logits(self, x, keep_prob=1.0, generator=None, engine=None):
+    def logits(self, x, keep_prob=1.0, generator=None, engine=None, masks=None):
         """x [N, 35] or [N, 35, 1] -> logits [N, 35].
 
         With ``engine`` (a fp32 HipEngine on the same GPU) the biGRU layers run on the native HIP
-        forward/backward kernels (catfish_amd/native_train.py); everything else stays torch autograd."""
+        forward/backward kernels (catfish_amd/native_train.py); everything else stays torch autograd.
+        ``masks`` ({(layer, "fw"|"bw"): 0/1 array [N, 35, 64]}) replaces the random dropout draws (tests)."""
         torch = self.torch
         p = self.params
         x = torch.as_tensor(x, dtype=self.dtype, device=self.device)
@@ -84,7 +85,11 @@ class TorchResNetRNN(object):
                       for k in ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")]
                 a = native_bigru(a, p8, engine)
                 if keep_prob < 1.0:                      # DropoutWrapper(output_keep_prob): outputs only
-                    mask = torch.floor(keep_prob + torch.rand(a.shape, generator=generator, device=self.device, dtype=self.dtype))
+                    if masks is not None:
+                        mask = torch.cat([torch.as_tensor(masks[(layer, d)], dtype=self.dtype, device=self.device)
+                                          for d in ("fw", "bw")], 2)
+                    else:
+                        mask = torch.floor(keep_prob + torch.rand(a.shape, generator=generator, device=self.device, dtype=self.dtype))
                     a = a / keep_prob * mask
                 continue
             outs = []
@@ -104,18 +109,21 @@ class TorchResNetRNN(object):
                     seq[s] = h
                 out = torch.stack(seq, 1)
                 if keep_prob < 1.0:                      # DropoutWrapper(output_keep_prob): outputs only
-                    mask = torch.floor(keep_prob + torch.rand(out.shape, generator=generator, device=self.device,
-                                                              dtype=self.dtype))
+                    if masks is not None:
+                        mask = torch.as_tensor(masks[(layer, dname)], dtype=self.dtype, device=self.device)
+                    else:
+                        mask = torch.floor(keep_prob + torch.rand(out.shape, generator=generator, device=self.device,
+                                                                  dtype=self.dtype))
                     out = out / keep_prob * mask
                 outs.append(out)
             a = torch.cat(outs, 2)
         return (a.reshape(-1, a.shape[2]) @ p["final_fully_connected/kernel"] +
                 p["final_fully_connected/bias"]).reshape(n, t_len)
 
-    def loss(self, x, y, keep_prob=1.0, generator=None, engine=None):
+    def loss(self, x, y, keep_prob=1.0, generator=None, engine=None, masks=None):
         """tf.losses.sigmoid_cross_entropy + reduce_mean (rnn_class.py:74-79)."""
         torch = self.torch
-        z = self.logits(x, keep_prob, generator, engine)
+        z = self.logits(x, keep_prob, generator, engine, masks)
         y = torch.as_tensor(y, dtype=self.dtype, device=self.device).reshape(z.shape)
         return torch.nn.functional.binary_cross_entropy_with_logits(z, y, reduction="mean")
 

@@ -278,6 +278,7 @@ class GraphInterpreter(object):
                 self.frame_pushes.setdefault(nodes[n.inputs[0][0]].attr["frame_name"], []).append(n.name)
         self.grad_arrays = {}
         self.updates = {}
+        self.trace = {}            # {node name: []}: every value the node takes (once per loop iteration), in run order
 
     def _through_identity(self, name):
         while self.nodes[name].op == "Identity":
@@ -337,6 +338,8 @@ class GraphInterpreter(object):
         outs = self._kernel(node, args)
         for i, o in enumerate(outs):
             ctx.memo[(name, i)] = o
+        if name in self.trace:
+            self.trace[name].append(outs[0])
         return outs[idx]
 
     def _run_loop(self, frame, ctx):

@@ -106,6 +106,50 @@ def train_trajectory(nodes, variables, store32=False, tag="train"):
     return out
 
 
+DROP_KEEP = 0.8          # the shipped ResNetRNN.txt keep_prob
+DROP_BATCH = 8
+
+
+def dropout_step(nodes, variables):
+    """One loss + gradient evaluation with LIVE dropout (keep_prob 0.8, the DropoutWrapper around every GRU cell,
+    rnn_class.py:146-152).  The masks the graph drew (its dropout/Floor nodes, per layer, direction and loop
+    iteration) are recorded so that a trainer can replay them."""
+    rng = np.random.RandomState(20260103)
+    x = (rng.randn(DROP_BATCH, 35) * 1.5).astype(np.float32)
+    y = (rng.rand(DROP_BATCH, 35) < 0.3).astype(np.float32)
+    gi = G.GraphInterpreter(nodes, variables, np.float64, seed=11)
+    floor = "recurrent_layer/stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/%s/while/dropout/Floor"
+    for layer in range(3):
+        for d in ("fw", "bw"):
+            gi.trace[floor % (layer, d, d)] = []
+    applies = sorted(k for k, n in nodes.items() if n.op == "ApplyRMSProp")
+    names = [nodes[a].inputs[0][0] for a in applies]
+    res = gi.run(["loss/Mean"] + ["%s:%d" % nodes[a].inputs[7] for a in applies],
+                 {"data/Placeholder": x.reshape(-1, 35, 1), "data/Placeholder_1": y.reshape(-1, 35, 1),
+                  "dropout": np.float32(DROP_KEEP)})
+    out = {"drop_x": x, "drop_y": y, "drop_keep_prob": np.float64(DROP_KEEP), "drop_loss": np.float64(res[0])}
+    masks = np.zeros((3, 2, DROP_BATCH, 35, 64), dtype=np.uint8)
+    for layer in range(3):
+        for di, d in enumerate(("fw", "bw")):
+            seq = gi.trace[floor % (layer, d, d)]
+            assert len(seq) == 35
+            for it, m in enumerate(seq):                       # the bw loop walks the time-reversed sequence
+                masks[layer, di, :, (34 - it) if d == "bw" else it, :] = m
+    out["drop_masks"] = masks
+    keep = ("conv1d/kernel", "conv1d_7/kernel", "batch_normalization_4/gamma", "final_fully_connected/kernel",
+            "stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/gru_cell/gates/kernel",
+            "stack_bidirectional_rnn/cell_1/bidirectional_rnn/bw/gru_cell/candidate/kernel",
+            "stack_bidirectional_rnn/cell_2/bidirectional_rnn/bw/gru_cell/gates/bias")
+    sums = {}
+    for k, g in zip(names, res[1:]):
+        g = np.asarray(g).reshape(np.asarray(variables[k]).shape)
+        sums[k] = [float(g.sum()), float(np.abs(g).sum())]
+        if k in keep:
+            out["drop_grad/" + k] = g.astype(np.float32)
+    out["drop_grad_sums_json"] = np.array(json.dumps(sums, sort_keys=True))
+    return out
+
+
 def summary(nodes):
     sub = G.inference_subgraph(nodes, FETCH)
     ops = {}
@@ -152,6 +196,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "graph_golden.npz"), **arrays)
     train = train_trajectory(nodes, variables)
     train.update(train_trajectory(nodes, variables, store32=True, tag="train32"))
+    train.update(dropout_step(nodes, variables))
     np.savez_compressed(os.path.join(HERE, "graph_train_golden.npz"), **train)
     print("train losses", train["train_loss"])
     sm = summary(nodes)

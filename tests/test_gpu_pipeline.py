@@ -325,6 +325,31 @@ def test_native_trainer_follows_the_reference_training_graph(ckpt_weights):
     tr.engine.close()
 
 
+def test_native_training_with_dropout_matches_the_reference_graph(ckpt_weights):
+    """keep_prob 0.8 with the masks the reference graph drew (graph_train_golden.npz, drop_*): loss and gradients
+    of the HIP training kernels + torch remainder against the interpreted reference graph."""
+    import os
+    torch = pytest.importorskip("torch")
+    from catfish_amd.training import TorchResNetRNN
+    from catfish_amd.engine import HipEngine
+    from conftest import GOLDEN
+    with np.load(os.path.join(GOLDEN, "graph_train_golden.npz")) as z:
+        g = {k: z[k] for k in z.files if k.startswith("drop_")}
+    masks = {(layer, d): g["drop_masks"][layer, di] for layer in range(3) for di, d in enumerate(("fw", "bw"))}
+    net = TorchResNetRNN(ckpt_weights, 3, 2, device="cuda")
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=256, fuse_layers=False)
+    try:
+        loss = net.loss(g["drop_x"], g["drop_y"], keep_prob=float(g["drop_keep_prob"]), engine=eng, masks=masks)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g["drop_loss"])) < 5e-6
+        for k in [n[len("drop_grad/"):] for n in g if n.startswith("drop_grad/")]:
+            ref = g["drop_grad/" + k]
+            got = net.params[k].grad.cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), k
+    finally:
+        eng.close()
+
+
 def test_cli_end_to_end(tmp_path, ckpt_weights, monkeypatch):
     """`catfish -i IN -s OUT -c 300` (catfish/catfish:18-94): model directory with ResNetRNN.txt + a TF
     checkpoint-V2 bundle (written here from the exported tensors), a directory of reads, chunk coordinates out."""

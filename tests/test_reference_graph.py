@@ -173,3 +173,31 @@ def test_restore_then_train_continues_from_the_saved_slots(tmp_path):
     back = checkpoint.read_optimizer_state(str(tmp_path), "ckpnt-1")
     assert set(back) == set(state)
     assert np.array_equal(back["conv1d/kernel/RMSProp"], tr.opt.ms["conv1d/kernel"].numpy().astype(np.float32))
+
+
+def test_dropout_wiring_matches_reference_graph(ckpt_weights, train_golden):
+    """keep_prob 0.8 (rnn_class.py:146-152): replaying the masks the reference graph drew, the restated
+    training graph gives the same loss and the same gradients -- dropout sits on each cell's OUTPUT only (the
+    carried state is not dropped), scaled by 1/keep_prob, and the mask multiplies the backward signal."""
+    import json
+    import torch
+    from catfish_amd.training import TorchResNetRNN
+    g = train_golden
+    masks = {(layer, d): g["drop_masks"][layer, di] for layer in range(3) for di, d in enumerate(("fw", "bw"))}
+    frac = float(g["drop_masks"].mean())
+    assert 0.78 < frac < 0.82                                   # keep_prob 0.8
+    net = TorchResNetRNN(ckpt_weights, 3, 2, device="cpu", dtype=torch.float64)
+    loss = net.loss(torch.from_numpy(g["drop_x"]).double(), torch.from_numpy(g["drop_y"]).double(),
+                    keep_prob=float(g["drop_keep_prob"]), masks=masks)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["drop_loss"])) < 1e-9
+    sums = json.loads(str(g["drop_grad_sums_json"]))
+    for k, p in net.trainable().items():
+        gr = p.grad.numpy()
+        scale = sums[k][1] + 1e-30
+        assert abs(gr.sum() - sums[k][0]) < 1e-7 * scale and abs(np.abs(gr).sum() - sums[k][1]) < 1e-7 * scale, k
+        if "drop_grad/" + k in g:
+            assert _close(gr, g["drop_grad/" + k], 1e-6), k
+    # without the masks (keep_prob 1) the loss is different: the test would notice a dropped wrapper
+    plain = float(net.loss(torch.from_numpy(g["drop_x"]).double(), torch.from_numpy(g["drop_y"]).double()).detach())
+    assert abs(plain - float(g["drop_loss"])) > 1e-4
