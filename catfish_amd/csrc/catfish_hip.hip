@@ -493,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void gru_fused_kernel(cf_fused_args a) {
 static_assert(gtb_pack_floats(32) == ((32 + CF_H) / 16 / 2) * 128 * 48 && gtb_pack_floats(128) == ((128 + CF_H) / 16 / 2) * 128 * 48,
               "gru_train_bwd_coop_kernel's PACK must equal gtb_pack_floats");
 #define CF_COOP_BWD_XCH_FLOATS (3 * 4 * 64 * 4)   // da_c, da_r, da_u exchange tiles
+#include "gru_wgrad.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1b: plain RNN type (no residual blocks, rnn_class.py:165-175 applied to the raw signal).
@@ -1423,7 +1424,8 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
 }
 
 extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
-                                     const float* dy_frag, float* dx_frag, float* da, int64_t n_windows, void* stream) {
+                                     const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
+                                     int64_t n_windows, void* stream) {
     if (!m || !wpack_bwd || !y_frag || !stash || !dy_frag || !dx_frag || !da)
         return fail(CF_ERR_INVALID, "cf_gru_train_backward: null argument");
     if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_backward: n_windows must be positive");
@@ -1437,11 +1439,13 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
         if (cin == CF_C)
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
-                               reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                               reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
         else
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
-                               reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                               reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
         HIP_TRY(hipGetLastError());
         return CF_OK;
     }
@@ -1450,11 +1454,57 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
     if (cin == CF_C)
         hipLaunchKernelGGL((gru_train_bwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(32) * 4, s, wpack_bwd,
                            reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
-                           reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                           reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
     else
         hipLaunchKernelGGL((gru_train_bwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(128) * 4, s, wpack_bwd,
                            reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
-                           reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                           reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+static int wgrad_pairs_per_wg(int n_pairs, int n_cu) {
+    // enough chunks to cover the chip once per direction, at least 4 pairs each so the partial sums stay small
+    return std::max(4, (n_pairs + n_cu - 1) / n_cu);
+}
+
+extern "C" int64_t cf_gru_wgrad_workspace_floats(cf_model* m, int32_t cin, int64_t n_windows) {
+    if (!m || (cin != CF_C && cin != 2 * CF_H) || n_windows <= 0) return 0;
+    const int n_pairs = (int)((n_windows + CF_TILE - 1) / CF_TILE) * CF_T;
+    const int ppw = wgrad_pairs_per_wg(n_pairs, m->n_cu);
+    const int64_t n_chunks = (n_pairs + ppw - 1) / ppw;
+    return n_chunks * 2 * gwg_partial_floats(cin);
+}
+
+extern "C" int cf_gru_train_wgrad(cf_model* m, int32_t cin, const float* x_frag, const float* y_frag, const float* stash,
+                                  const float* da, int64_t n_windows, float* workspace, int64_t workspace_floats, float* grads,
+                                  void* stream) {
+    if (!m || !x_frag || !y_frag || !stash || !da || !workspace || !grads)
+        return fail(CF_ERR_INVALID, "cf_gru_train_wgrad: null argument");
+    if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_wgrad: n_windows must be positive");
+    int rc = train_cin_ok(m, cin);
+    if (rc != CF_OK) return rc;
+    if (workspace_floats < cf_gru_wgrad_workspace_floats(m, cin, n_windows))
+        return fail(CF_ERR_INVALID, "cf_gru_train_wgrad: workspace too small (see cf_gru_wgrad_workspace_floats)");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    const int n_pairs = n_tiles * CF_T;
+    const int ppw = wgrad_pairs_per_wg(n_pairs, m->n_cu);
+    const int n_chunks = (n_pairs + ppw - 1) / ppw;
+    if (cin == CF_C)
+        hipLaunchKernelGGL((gru_wgrad_kernel<32>), dim3(n_chunks, 2), dim3(CF_WGRAD_WAVES * 64), 0, s, reinterpret_cast<const f32x4*>(x_frag),
+                           reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash), reinterpret_cast<const f32x4*>(da),
+                           workspace, n_tiles, ppw);
+    else
+        hipLaunchKernelGGL((gru_wgrad_kernel<128>), dim3(n_chunks, 2), dim3(CF_WGRAD_WAVES * 64), 0, s, reinterpret_cast<const f32x4*>(x_frag),
+                           reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash), reinterpret_cast<const f32x4*>(da),
+                           workspace, n_tiles, ppw);
+    HIP_TRY(hipGetLastError());
+    const int per = gwg_partial_floats(cin);
+    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((per + 255) / 256, 2), dim3(256), 0, s, workspace, grads, gwg_rows(cin), n_chunks);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }

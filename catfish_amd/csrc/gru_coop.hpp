@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float*
 // ------------------------------------------------------------------------------------------
 template <int CIN, int W>
 __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ Y,
-                                                  const f32x4* __restrict__ S, const f32x4* __restrict__ DY, f32x4* __restrict__ DX,
+                                                  const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
+                                                  const f32x4* __restrict__ DY2, const f32x4* __restrict__ DSC, f32x4* __restrict__ DX,
                                                   f32x4* __restrict__ DA, int n_tiles) {
     constexpr int MI = (CIN + CF_H) / 16;
     constexpr int MX = CIN / 16;
@@ -204,7 +205,10 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
         const int64_t base = (int64_t)tile * CF_T + t;
         const f32x4* sp = S + (base * 2 + dir) * 12 * 64 + lane;
         const f32x4 r = sp[(0 + W) * 64], u = sp[(4 + W) * 64], c = sp[(8 + W) * 64];
-        const f32x4 dh = dhc + DY[(base * 8 + dir * 4 + W) * 64 + lane];
+        f32x4 dy = DY[(base * 8 + dir * 4 + W) * 64 + lane];
+        if (DY2) dy += DY2[(base * 8 + dir * 4 + W) * 64 + lane];
+        if (DSC) dy *= DSC[(base * 8 + dir * 4 + W) * 64 + lane];
+        const f32x4 dh = dhc + dy;
         f32x4 hp = {0, 0, 0, 0};
         if (s > 0) hp = Y[(((int64_t)tile * CF_T + tp) * 8 + dir * 4 + W) * 64 + lane];
         const f32x4 du = dh * (hp - c);
@@ -265,6 +269,7 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
 template <int CIN>
 __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ Y,
                                                                     const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
+                                                                    const f32x4* __restrict__ DY2, const f32x4* __restrict__ DSC,
                                                                     f32x4* __restrict__ DX, f32x4* __restrict__ DA, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = ((CIN + CF_H) / 16 / 2) * 128 * 48;      // = gtb_pack_floats(CIN)
@@ -281,10 +286,10 @@ __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float*
     float* xch = lds + PACK;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         switch (wave) {
-            case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
-            case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
-            case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
-            default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DX, DA, n_tiles); break;
+            case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+            case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+            case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+            default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
         }
     }
 }

@@ -43,6 +43,8 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
                                                                const f32x4* __restrict__ Y,       // layer output  [tile][t][8][lane]
                                                                const f32x4* __restrict__ S,       // stash         [tile][t][2][12][lane]
                                                                const f32x4* __restrict__ DY,      // d loss / d Y  [tile][t][8][lane]
+                                                               const f32x4* __restrict__ DY2,     // optional second addend of dY (same layout)
+                                                               const f32x4* __restrict__ DSC,     // optional per-element scale of dY (dropout mask / keep_prob)
                                                                f32x4* __restrict__ DX,            // [2 dirs][tile][t][CIN/16][lane]
                                                                f32x4* __restrict__ DA,            // [tile][t][2][12][lane]: da_r, da_u (0..7), da_c (8..11)
                                                                int n_tiles) {
@@ -75,7 +77,13 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
                 const f32x4* sp = S + (base * 2 + dir) * 12 * 64 + lane;
                 const f32x4* dyp = DY + (base * 8 + dir * 4) * 64 + lane;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { r[m] = sp[m * 64]; u[m] = sp[(4 + m) * 64]; c[m] = sp[(8 + m) * 64]; dh[m] = dhc[m] + dyp[m * 64]; }
+                for (int m = 0; m < 4; ++m) {
+                    r[m] = sp[m * 64]; u[m] = sp[(4 + m) * 64]; c[m] = sp[(8 + m) * 64];
+                    f32x4 dy = dyp[m * 64];
+                    if (DY2) dy += DY2[(base * 8 + dir * 4 + m) * 64 + lane];
+                    if (DSC) dy *= DSC[(base * 8 + dir * 4 + m) * 64 + lane];
+                    dh[m] = dhc[m] + dy;
+                }
                 if (s > 0) {
                     const f32x4* hpp = Y + (((int64_t)tile * CF_T + tp) * 8 + dir * 4) * 64 + lane;
 #pragma unroll

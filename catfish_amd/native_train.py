@@ -104,7 +104,7 @@ def _make_function():
             da = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             N.check(lib.cf_gru_train_backward(handle, int(cin), C.c_void_p(wpack_bwd.data_ptr()), C.c_void_p(y_frag.data_ptr()),
-                                              C.c_void_p(stash.data_ptr()), C.c_void_p(dy_frag.data_ptr()),
+                                              C.c_void_p(stash.data_ptr()), C.c_void_p(dy_frag.data_ptr()), None, None,
                                               C.c_void_p(dx_frag.data_ptr()), C.c_void_p(da.data_ptr()), npad, C.c_void_p(stream)))
             dx = (frag_to_nat(dx_frag[0]) + frag_to_nat(dx_frag[1]))[:n]
             y = frag_to_nat(y_frag)                                   # [npad, 35, 128]
@@ -138,3 +138,161 @@ def native_bigru(x, params8, engine):
     if _FN is None:
         _FN = _make_function()
     return _FN.apply(x, *params8, engine)
+
+
+# ------------------------------------------------------------------------------------------------
+# The whole biGRU stack, fragment-resident (what the Trainer uses)
+# ------------------------------------------------------------------------------------------------
+_STACK_MAPS = {}
+
+
+def _stack_maps(cins, device):
+    """One gather map for ALL layers, directions and both packings: packed = cat(blocks)[idx] * scale, where the
+    source is the concatenation of per-(layer, direction) blocks [gates_kernel | candidate_kernel | gates_bias |
+    candidate_bias | 0.0].  Returns (idx, scale, [(fwd_offset, fwd_floats, bwd_offset, bwd_floats) per layer])."""
+    import torch
+    key = (tuple(cins), str(device))
+    if key not in _STACK_MAPS:
+        idxs, scales, layout = [], [], []
+        src_off = 0
+        out_off = 0
+        fwd_parts, bwd_parts = [], []
+        for cin in cins:
+            idx_f, sc_f, idx_b, sc_b = pack_maps(cin, device)
+            block = (cin + 64) * 192 + 192 + 1                       # wg + wc + bg + bc + the zero slot
+            fwd_parts.append([(idx_f + src_off + d * block, sc_f) for d in range(2)])
+            bwd_parts.append([(idx_b + src_off + d * block, sc_b) for d in range(2)])
+            src_off += 2 * block
+        for parts in (fwd_parts, bwd_parts):
+            offs = []
+            for layer in parts:
+                n = sum(int(i.numel()) for i, _ in layer)
+                offs.append((out_off, n))
+                for i, sc in layer:
+                    idxs.append(i)
+                    scales.append(sc)
+                out_off += n
+            layout.append(offs)
+        per_layer = [(layout[0][k][0], layout[0][k][1], layout[1][k][0], layout[1][k][1]) for k in range(len(cins))]
+        _STACK_MAPS[key] = (torch.cat(idxs), torch.cat(scales), per_layer)
+    return _STACK_MAPS[key]
+
+
+def _make_stack_function():
+    import torch
+
+    class NativeGRUStack(torch.autograd.Function):
+        """y = dropout(biGRU_L(... dropout(biGRU_1(x)) ...)); x [N,35,Cin0] -> y [N,35,128].
+
+        Activations stay in the MFMA fragment layout between the layers; per layer one forward launch, one
+        backward launch (the two direction slabs of the layer above are added, and the dropout factor applied,
+        inside it) and one weight-gradient launch.  ``drop``: None, or one [npad/16,35,8,64,4] tensor per layer
+        holding mask / keep_prob in fragment layout (DropoutWrapper(output_keep_prob), rnn_class.py:151-154)."""
+
+        @staticmethod
+        def forward(ctx, x, engine, drop, *params):
+            lib, handle = engine._lib, engine._handle
+            n_layers = len(params) // 8
+            dev = x.device
+            cins = [int(x.shape[2])] + [128] * (n_layers - 1)
+            idx, scale, per_layer = _stack_maps(cins, dev)
+            with torch.no_grad():
+                zero = x.new_zeros(1, dtype=torch.float32)
+                blocks = []
+                for layer in range(n_layers):
+                    for d in range(2):
+                        wg, bg, wc, bc = params[8 * layer + 4 * d:8 * layer + 4 * d + 4]
+                        blocks += [wg.reshape(-1), wc.reshape(-1), bg.reshape(-1), bc.reshape(-1), zero]
+                packed = torch.cat(blocks).float()[idx] * scale
+            n = x.shape[0]
+            npad = (n + 15) // 16 * 16
+            tiles = npad // 16
+            xp = x if npad == n else torch.cat([x, x.new_zeros(npad - n, T, cins[0])], 0)
+            cur = nat_to_frag(xp.float())
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            saved = []
+            for layer in range(n_layers):
+                fo, fn, _, _ = per_layer[layer]
+                y_frag = torch.empty(tiles, T, 8, 64, 4, dtype=torch.float32, device=dev)
+                stash = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=dev)
+                N.check(lib.cf_gru_train_forward(handle, cins[layer], C.c_void_p(packed[fo:fo + fn].data_ptr()),
+                                                 C.c_void_p(cur.data_ptr()), C.c_void_p(y_frag.data_ptr()),
+                                                 C.c_void_p(stash.data_ptr()), npad, stream))
+                saved += [cur, y_frag, stash]
+                cur = y_frag if drop is None else y_frag * drop[layer]
+            ctx.engine, ctx.n, ctx.npad, ctx.cins, ctx.per_layer = engine, n, npad, cins, per_layer
+            ctx.drop = drop
+            ctx.save_for_backward(packed, *saved)
+            return frag_to_nat(cur)[:n]
+
+        @staticmethod
+        def backward(ctx, dy):
+            packed = ctx.saved_tensors[0]
+            saved = ctx.saved_tensors[1:]
+            engine, n, npad, cins, per_layer, drop = ctx.engine, ctx.n, ctx.npad, ctx.cins, ctx.per_layer, ctx.drop
+            lib, handle = engine._lib, engine._handle
+            dev = dy.device
+            tiles = npad // 16
+            n_layers = len(cins)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            dyp = dy if npad == n else torch.cat([dy, dy.new_zeros(npad - n, T, dy.shape[2])], 0)
+            g0 = nat_to_frag(dyp.float().contiguous())
+            g1 = None
+            grads = [None] * (8 * n_layers)
+            for layer in range(n_layers - 1, -1, -1):
+                cin = cins[layer]
+                x_frag, y_frag, stash = saved[3 * layer:3 * layer + 3]
+                _, _, bo, bn = per_layer[layer]
+                dx_frag = torch.empty(2, tiles, T, cin // 16, 64, 4, dtype=torch.float32, device=dev)
+                da = torch.empty(tiles, T, 2, 12, 64, 4, dtype=torch.float32, device=dev)
+                N.check(lib.cf_gru_train_backward(
+                    handle, cin, C.c_void_p(packed[bo:bo + bn].data_ptr()), C.c_void_p(y_frag.data_ptr()), C.c_void_p(stash.data_ptr()),
+                    C.c_void_p(g0.data_ptr()), None if g1 is None else C.c_void_p(g1.data_ptr()),
+                    None if drop is None else C.c_void_p(drop[layer].data_ptr()),
+                    C.c_void_p(dx_frag.data_ptr()), C.c_void_p(da.data_ptr()), npad, stream))
+                ws_floats = int(lib.cf_gru_wgrad_workspace_floats(handle, cin, npad))
+                ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+                rows = cin + 64
+                out = torch.empty(2, rows * 192 + 192, dtype=torch.float32, device=dev)
+                N.check(lib.cf_gru_train_wgrad(handle, cin, C.c_void_p(x_frag.data_ptr()), C.c_void_p(y_frag.data_ptr()),
+                                               C.c_void_p(stash.data_ptr()), C.c_void_p(da.data_ptr()), npad,
+                                               C.c_void_p(ws.data_ptr()), ws_floats, C.c_void_p(out.data_ptr()), stream))
+                for d in range(2):
+                    o = out[d]
+                    grads[8 * layer + 4 * d + 0] = o[:rows * 128].view(rows, 128)
+                    grads[8 * layer + 4 * d + 1] = o[rows * 128:rows * 128 + 128]
+                    grads[8 * layer + 4 * d + 2] = o[rows * 128 + 128:rows * 128 + 128 + rows * 64].view(rows, 64)
+                    grads[8 * layer + 4 * d + 3] = o[rows * 128 + 128 + rows * 64:]
+                g0, g1 = dx_frag[0], dx_frag[1]
+            dx = frag_to_nat(g0 + g1)[:n]
+            return (dx.to(dy.dtype), None, None) + tuple(grads)
+
+    return NativeGRUStack
+
+
+_STACK_FN = None
+
+
+def dropout_scale_frag(npad, keep_prob, device, masks=None, layer=None):
+    """mask / keep_prob for one layer's [npad, 35, 128] output, in fragment layout.  ``masks`` (tests):
+    {(layer, "fw"|"bw"): 0/1 array [n, 35, 64]} replaces the random draw."""
+    import torch
+    if masks is not None:
+        m = torch.cat([torch.as_tensor(np.asarray(masks[(layer, d)]), dtype=torch.float32, device=device) for d in ("fw", "bw")], 2)
+        if m.shape[0] < npad:
+            m = torch.cat([m, m.new_zeros(npad - m.shape[0], T, 128)], 0)
+        return nat_to_frag(m) / keep_prob
+    return torch.floor(keep_prob + torch.rand(npad // 16, T, 8, 64, 4, device=device, dtype=torch.float32)) / keep_prob
+
+
+def native_gru_stack(x, params, engine, keep_prob=1.0, masks=None):
+    """Differentiable stack of biGRU layers on the HIP kernels.  params: 8 tensors per layer
+    (wg_f, bg_f, wc_f, bc_f, wg_b, bg_b, wc_b, bc_b), x: [N, 35, Cin0] -> [N, 35, 128]."""
+    global _STACK_FN
+    if _STACK_FN is None:
+        _STACK_FN = _make_stack_function()
+    drop = None
+    if keep_prob < 1.0:
+        npad = (int(x.shape[0]) + 15) // 16 * 16
+        drop = [dropout_scale_frag(npad, keep_prob, x.device, masks, layer) for layer in range(len(params) // 8)]
+    return _STACK_FN.apply(x, engine, drop, *params)

@@ -77,21 +77,13 @@ class TorchResNetRNN(object):
             a = torch.relu(o + sc)
         a = a.permute(0, 2, 1)                           # [N, T, C]
         n, t_len, _ = a.shape
-        for layer in range(self.n_layers):
-            if engine is not None:
-                from .native_train import native_bigru
-                pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell"
-                p8 = [p[(pre % (layer, d)) + k] for d in ("fw", "bw")
-                      for k in ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")]
-                a = native_bigru(a, p8, engine)
-                if keep_prob < 1.0:                      # DropoutWrapper(output_keep_prob): outputs only
-                    if masks is not None:
-                        mask = torch.cat([torch.as_tensor(masks[(layer, d)], dtype=self.dtype, device=self.device)
-                                          for d in ("fw", "bw")], 2)
-                    else:
-                        mask = torch.floor(keep_prob + torch.rand(a.shape, generator=generator, device=self.device, dtype=self.dtype))
-                    a = a / keep_prob * mask
-                continue
+        if engine is not None:                           # all biGRU layers on the HIP training kernels
+            from .native_train import native_gru_stack
+            pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell"
+            plist = [p[(pre % (layer, d)) + k] for layer in range(self.n_layers) for d in ("fw", "bw")
+                     for k in ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")]
+            a = native_gru_stack(a, plist, engine, keep_prob, masks)
+        for layer in range(self.n_layers if engine is None else 0):
             outs = []
             for dname, rev in (("fw", False), ("bw", True)):
                 pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell" % (layer, dname)

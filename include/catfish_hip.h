@@ -153,9 +153,13 @@ int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets,
  *   y_frag   [tiles][35][8][64][4]           layer output (M-tiles 0-3 forward, 4-7 backward direction)
  *   stash    [tiles][35][2][12][64][4]       activated r, u gates and candidate c of every step
  *   dy_frag  like y_frag                     gradient of the loss w.r.t. the layer output
+ *   dy2_frag like y_frag, or NULL            second addend of that gradient (the other direction's dx slab of the
+ *                                            layer above, so no separate add pass is needed)
+ *   dy_scale like y_frag, or NULL            per-element factor applied to dy (+ dy2): the output-dropout mask
+ *                                            divided by keep_prob (DropoutWrapper, rnn_class.py:151-154)
  *   dx_frag  [2][tiles][35][cin/16][64][4]   gradient w.r.t. the layer input, one slab per direction (add them)
  *   da       like stash                      pre-activation gradients da_r, da_u (0-7), da_c (8-11); the weight
- *                                            gradients are dW = A^T dA, formed by the caller with a library GEMM
+ *                                            gradients are dW = A^T dA (cf_gru_train_wgrad)
  * wpack / wpack_bwd: device pointers to the re-tiled weights of BOTH directions ([2][n_floats]), owned by the
  * caller.  cf_gru_pack_map returns the gather map of that re-tiling for one direction, so a trainer can
  * rebuild them on device after every optimizer step: packed[i] = src[idx[i]] * scale[i] with
@@ -165,7 +169,15 @@ int cf_gru_pack_map(int32_t cin, int32_t backward, int32_t* idx, float* scale, i
 int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag,
                          float* stash, int64_t n_windows, void* stream);
 int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
-                          const float* dy_frag, float* dx_frag, float* da, int64_t n_windows, void* stream);
+                          const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
+                          int64_t n_windows, void* stream);
+/* dW of one biGRU layer from the fragment buffers (the weight-gradient half of optimizer.minimize(loss),
+ * catfish/models/rnn_class.py:62-71): grads = per direction [ gates kernel [cin+64,128] | gates bias [128] |
+ * candidate kernel [cin+64,64] | candidate bias [64] ] in TensorFlow layout, 2 directions back to back.
+ * workspace: cf_gru_wgrad_workspace_floats(m, cin, n_windows) floats of device scratch (0 = bad arguments). */
+int64_t cf_gru_wgrad_workspace_floats(cf_model* m, int32_t cin, int64_t n_windows);
+int cf_gru_train_wgrad(cf_model* m, int32_t cin, const float* x_frag, const float* y_frag, const float* stash, const float* da,
+                       int64_t n_windows, float* workspace, int64_t workspace_floats, float* grads, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, N) makes every N-th cf_infer call
