@@ -79,6 +79,11 @@ SYMBOLS = {
     "cf_gru_wgrad_workspace_floats": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64]),
     "cf_gru_train_wgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cf_res_train_param_floats": (C.c_int64, [C.c_int32]),
+    "cf_res_train_workspace_floats": (C.c_int64, [C.c_int32, C.c_int64]),
+    "cf_res_train_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cf_res_train_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
     "cf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cf_profile_reset": (C.c_int, [C.c_void_p]),
     "cf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

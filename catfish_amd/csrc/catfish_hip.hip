@@ -494,6 +494,7 @@ static_assert(gtb_pack_floats(32) == ((32 + CF_H) / 16 / 2) * 128 * 48 && gtb_pa
               "gru_train_bwd_coop_kernel's PACK must equal gtb_pack_floats");
 #define CF_COOP_BWD_XCH_FLOATS (3 * 4 * 64 * 4)   // da_c, da_r, da_u exchange tiles
 #include "gru_wgrad.hpp"
+#include "res_train.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1b: plain RNN type (no residual blocks, rnn_class.py:165-175 applied to the raw signal).
@@ -1505,6 +1506,70 @@ extern "C" int cf_gru_train_wgrad(cf_model* m, int32_t cin, const float* x_frag,
     HIP_TRY(hipGetLastError());
     const int per = gwg_partial_floats(cin);
     hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((per + 255) / 256, 2), dim3(256), 0, s, workspace, grads, gwg_rows(cin), n_chunks);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+// ---- residual conv stack, training ---------------------------------------------------------
+static int res_train_ok(const cf_model* m, int n_blocks) {
+    if (n_blocks < 1 || 4 * n_blocks > RT_MAX_UNITS) return fail(CF_ERR_INVALID, "residual training kernels: 1..4 blocks");
+    if (m->hp.layer_size_res != CF_C) return fail(CF_ERR_INVALID, "residual training kernels: 32 conv channels only");
+    return CF_OK;
+}
+
+extern "C" int64_t cf_res_train_param_floats(int32_t n_blocks) {
+    if (n_blocks < 1 || 4 * n_blocks > RT_MAX_UNITS) return 0;
+    return rt_make_layout(n_blocks).off[4 * n_blocks];
+}
+
+extern "C" int64_t cf_res_train_workspace_floats(int32_t n_blocks, int64_t n_windows) {
+    if (n_blocks < 1 || 4 * n_blocks > RT_MAX_UNITS || n_windows <= 0) return 0;
+    return ((n_windows + RT_WIN - 1) / RT_WIN) * (int64_t)rt_make_layout(n_blocks).off[4 * n_blocks];
+}
+
+extern "C" int cf_res_train_forward(cf_model* m, int32_t n_blocks, const float* params, const float* x, float* z_stash, float* out,
+                                    int64_t n_windows, void* stream) {
+    if (!m || !params || !x || !z_stash || !out) return fail(CF_ERR_INVALID, "cf_res_train_forward: null argument");
+    if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_res_train_forward: n_windows must be positive");
+    int rc = res_train_ok(m, n_blocks);
+    if (rc != CF_OK) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    static bool opted = false;
+    if (!opted) {
+        HIP_TRY(hipFuncSetAttribute((const void*)res_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RT_POS * 32 * 4));
+        opted = true;
+    }
+    const int n_wg = (int)((n_windows + RT_WIN - 1) / RT_WIN);
+    hipLaunchKernelGGL(res_train_fwd_kernel, dim3(n_wg), dim3(RT_THREADS), 4 * RT_POS * 32 * 4, reinterpret_cast<hipStream_t>(stream), x, params,
+                       z_stash, out, rt_make_layout(n_blocks), (int)n_windows, n_blocks, m->hp.bn_epsilon);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+extern "C" int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float* params, const float* x, const float* z_stash,
+                                     const float* d_out, float* workspace, int64_t workspace_floats, float* grads, int64_t n_windows,
+                                     void* stream) {
+    if (!m || !params || !x || !z_stash || !d_out || !workspace || !grads) return fail(CF_ERR_INVALID, "cf_res_train_backward: null argument");
+    if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_res_train_backward: n_windows must be positive");
+    int rc = res_train_ok(m, n_blocks);
+    if (rc != CF_OK) return rc;
+    if (workspace_floats < cf_res_train_workspace_floats(n_blocks, n_windows))
+        return fail(CF_ERR_INVALID, "cf_res_train_backward: workspace too small (see cf_res_train_workspace_floats)");
+    HIP_TRY(hipSetDevice(m->device));
+    const int lds_bytes = (5 * RT_POS * 32 + 3 * 32 * 32 + 96) * 4;
+    static bool opted = false;
+    if (!opted) {
+        HIP_TRY(hipFuncSetAttribute((const void*)res_train_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        opted = true;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const rt_layout L = rt_make_layout(n_blocks);
+    const int n_wg = (int)((n_windows + RT_WIN - 1) / RT_WIN);
+    hipLaunchKernelGGL(res_train_bwd_kernel, dim3(n_wg), dim3(RT_THREADS), lds_bytes, s, x, params, z_stash, d_out, workspace, L,
+                       (int)n_windows, n_blocks, m->hp.bn_epsilon);
+    HIP_TRY(hipGetLastError());
+    const int nf = L.off[4 * n_blocks];
+    hipLaunchKernelGGL(res_train_reduce_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, workspace, grads, nf, n_wg);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }

@@ -296,3 +296,78 @@ def native_gru_stack(x, params, engine, keep_prob=1.0, masks=None):
         npad = (int(x.shape[0]) + 15) // 16 * 16
         drop = [dropout_scale_frag(npad, keep_prob, x.device, masks, layer) for layer in range(len(params) // 8)]
     return _STACK_FN.apply(x, engine, drop, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# The residual conv stack (resnet_class.py:44-82) on the HIP training kernels
+# ------------------------------------------------------------------------------------------------
+def res_unit_names(n_blocks):
+    """TF variable names per conv+BN unit, in the order of the kernels' parameter buffer (include/catfish_hip.h)."""
+    conv = lambda j: "conv1d" if j == 0 else "conv1d_%d" % j                                  # noqa: E731
+    bn = lambda j: "batch_normalization" if j == 0 else "batch_normalization_%d" % j         # noqa: E731
+    out = []
+    for j in range(4 * n_blocks):
+        out.append([conv(j) + "/kernel", conv(j) + "/bias", bn(j) + "/gamma", bn(j) + "/beta", bn(j) + "/moving_mean",
+                    bn(j) + "/moving_variance"])
+    return out
+
+
+def _make_res_function():
+    import torch
+
+    class NativeResStack(torch.autograd.Function):
+        """out = residual_blocks(x); x [N,35] -> [N,35,32].  params: 6 tensors per unit (res_unit_names order)."""
+
+        @staticmethod
+        def forward(ctx, x, engine, *params):
+            lib, handle = engine._lib, engine._handle
+            n_blocks = len(params) // 24
+            dev = x.device
+            n = int(x.shape[0])
+            with torch.no_grad():
+                prm = torch.cat([p.reshape(-1) for p in params]).float()
+            assert prm.numel() == lib.cf_res_train_param_floats(n_blocks)
+            xc = x.float().contiguous()
+            z = torch.empty(4 * n_blocks, n * T, 32, dtype=torch.float32, device=dev)
+            out = torch.empty(n, T, 32, dtype=torch.float32, device=dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            N.check(lib.cf_res_train_forward(handle, n_blocks, C.c_void_p(prm.data_ptr()), C.c_void_p(xc.data_ptr()),
+                                             C.c_void_p(z.data_ptr()), C.c_void_p(out.data_ptr()), n, stream))
+            ctx.engine, ctx.n_blocks, ctx.shapes = engine, n_blocks, [tuple(p.shape) for p in params]
+            ctx.save_for_backward(prm, xc, z)
+            return out
+
+        @staticmethod
+        def backward(ctx, dout):
+            prm, xc, z = ctx.saved_tensors
+            engine, n_blocks = ctx.engine, ctx.n_blocks
+            lib, handle = engine._lib, engine._handle
+            dev = dout.device
+            n = int(xc.shape[0])
+            ws_floats = int(lib.cf_res_train_workspace_floats(n_blocks, n))
+            ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+            grads = torch.empty_like(prm)
+            d = dout.float().contiguous()
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            N.check(lib.cf_res_train_backward(handle, n_blocks, C.c_void_p(prm.data_ptr()), C.c_void_p(xc.data_ptr()),
+                                              C.c_void_p(z.data_ptr()), C.c_void_p(d.data_ptr()), C.c_void_p(ws.data_ptr()), ws_floats,
+                                              C.c_void_p(grads.data_ptr()), n, stream))
+            outs, off = [], 0
+            for i, shp in enumerate(ctx.shapes):
+                cnt = int(np.prod(shp))
+                outs.append(None if i % 6 >= 4 else grads[off:off + cnt].view(shp))      # moving statistics do not train
+                off += cnt
+            return (None, None) + tuple(outs)
+
+    return NativeResStack
+
+
+_RES_FN = None
+
+
+def native_res_stack(x, params, engine):
+    """Differentiable residual conv stack on the HIP kernels: x [N,35] -> [N,35,32]."""
+    global _RES_FN
+    if _RES_FN is None:
+        _RES_FN = _make_res_function()
+    return _RES_FN.apply(x, engine, *params)

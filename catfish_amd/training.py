@@ -68,14 +68,19 @@ class TorchResNetRNN(object):
         if x.dim() == 3:
             x = x[:, :, 0]
         a = x[:, None, :]                                # [N, C, T]
-        for d in range(self.n_layers_res):
+        native_res = engine is not None and self.n_layers_res > 0 and self.dtype == torch.float32
+        if native_res:                                   # residual conv stack on the HIP training kernels
+            from .native_train import native_res_stack, res_unit_names
+            a = native_res_stack(x, [p[k] for unit in res_unit_names(self.n_layers_res) for k in unit], engine)
+        for d in range(0 if native_res else self.n_layers_res):
             j0 = 4 * d
             sc = self._conv_bn(a, j0)
             o = torch.relu(self._conv_bn(a, j0 + 1))
             o = torch.relu(self._conv_bn(o, j0 + 2))
             o = torch.relu(self._conv_bn(o, j0 + 3))
             a = torch.relu(o + sc)
-        a = a.permute(0, 2, 1)                           # [N, T, C]
+        if not native_res:
+            a = a.permute(0, 2, 1)                       # [N, T, C]
         n, t_len, _ = a.shape
         if engine is not None:                           # all biGRU layers on the HIP training kernels
             from .native_train import native_gru_stack

@@ -179,6 +179,23 @@ int64_t cf_gru_wgrad_workspace_floats(cf_model* m, int32_t cin, int64_t n_window
 int cf_gru_train_wgrad(cf_model* m, int32_t cin, const float* x_frag, const float* y_frag, const float* stash, const float* da,
                        int64_t n_windows, float* workspace, int64_t workspace_floats, float* grads, void* stream);
 
+/* Residual conv stack for training (forward catfish/models/resnet_class.py:44-82 with a stash of the conv outputs;
+ * backward = its share of optimizer.minimize(loss), rnn_class.py:62-71).  All pointers are device pointers.
+ *   params  cf_res_train_param_floats(n_blocks) floats: per conv+BN unit (4 per block, kernel widths 1,1,3,1)
+ *           kernel [k][cin][32] | bias[32] | gamma[32] | beta[32] | moving_mean[32] | moving_variance[32], TF layouts,
+ *           units back to back; cin = 1 for the first two units, 32 afterwards
+ *   x       [n_windows][35] fp32            z_stash [4 n_blocks][n_windows*35][32]     out / d_out [n_windows*35][32]
+ *   grads   same offsets as params (kernel, bias, gamma, beta gradients; the moving statistics get 0)
+ *   workspace  cf_res_train_workspace_floats(n_blocks, n_windows) floats of scratch (per-workgroup partial sums,
+ *           added in a fixed order) */
+int64_t cf_res_train_param_floats(int32_t n_blocks);
+int64_t cf_res_train_workspace_floats(int32_t n_blocks, int64_t n_windows);
+int cf_res_train_forward(cf_model* m, int32_t n_blocks, const float* params, const float* x, float* z_stash, float* out,
+                         int64_t n_windows, void* stream);
+int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float* params, const float* x, const float* z_stash,
+                          const float* d_out, float* workspace, int64_t workspace_floats, float* grads, int64_t n_windows,
+                          void* stream);
+
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, N) makes every N-th cf_infer call
  * (N = 1: every call; 0 = off) record events around each of its kernels; cf_profile_read synchronises and returns, for

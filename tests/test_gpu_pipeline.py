@@ -284,6 +284,41 @@ def test_native_gru_training_kernels_match_torch_autograd(n):
         eng.close()
 
 
+@pytest.mark.parametrize("n,n_blocks", [(41, 2), (3, 1), (130, 3)])
+def test_native_res_stack_training_kernels_match_torch_autograd(n, n_blocks):
+    """cf_res_train_forward/backward (resnet_class.py:44-82 and its gradients) against torch autograd of the
+    restated blocks: output and every kernel / bias / gamma / beta gradient; ragged window counts."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.training import TorchResNetRNN
+    from catfish_amd.engine import HipEngine
+    from catfish_amd.native_train import native_res_stack, res_unit_names
+    w = oracle.random_weights(seed=17, n_layers=1, n_layers_res=n_blocks)
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.normal(0, 1.2, size=(n, 35)).astype(np.float32)).cuda()
+    net = TorchResNetRNN(w, 1, n_blocks, device="cuda")
+    eng = HipEngine(w, n_layers=1, n_layers_res=n_blocks, device=0, max_windows_per_pass=256, fuse_layers=False)
+    try:
+        a = x[:, None, :]
+        for d in range(n_blocks):
+            sc = net._conv_bn(a, 4 * d)
+            o = torch.relu(net._conv_bn(a, 4 * d + 1))
+            o = torch.relu(net._conv_bn(o, 4 * d + 2))
+            o = torch.relu(net._conv_bn(o, 4 * d + 3))
+            a = torch.relu(o + sc)
+        ref = a.permute(0, 2, 1)
+        names = [k for unit in res_unit_names(n_blocks) for k in unit]
+        got = native_res_stack(x, [net.params[k] for k in names], eng)
+        assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+        g = torch.randn_like(ref)
+        train = [k for k in names if net.params[k].requires_grad]
+        gr_ref = torch.autograd.grad((ref * g).sum(), [net.params[k] for k in train], retain_graph=True)
+        gr_got = torch.autograd.grad((got * g).sum(), [net.params[k] for k in train])
+        for k, r, h in zip(train, gr_ref, gr_got):
+            assert float((r - h).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6, k
+    finally:
+        eng.close()
+
+
 def test_native_trainer_follows_the_torch_trainer():
     pytest.importorskip("torch")
     from catfish_amd.training import Trainer

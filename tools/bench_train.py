@@ -59,7 +59,7 @@ def main():
                 t2.train_step(x, y)
             torch.cuda.synchronize()
             modes[name + "_ms_per_step"] = (time.perf_counter() - t1) / 5 * 1e3
-    print(json.dumps({"metric": "training windows/s (config 5: native HIP biGRU fwd/bwd + torch autograd for the rest, TF-style Adam)",
+    print(json.dumps({"metric": "training windows/s (config 5: native HIP conv-stack and biGRU fwd/bwd/wgrad kernels; dense head, loss and optimizer in torch, TF-style Adam)",
                       "device": dev, "native": bool(getattr(tr, "native", False)), "other_modes": modes,
                       "batch": B, "value": n * B / dt, "ms_per_step": dt / n * 1e3,
                       "loss_10_steps_device": lg, "loss_10_steps_cpu": lc,
