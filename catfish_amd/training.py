@@ -235,7 +235,10 @@ class Trainer(object):
                  seed=None, use_graph=None, native=None, optimizer_state=None, dtype=None):
         import torch
         if device is None:
-            device = "cuda" if torch.cuda.is_available() else "cpu"
+            if not torch.cuda.is_available():
+                # no silent CPU fallback: the torch-CPU mode exists as the reference for tests and is opt-in
+                raise RuntimeError("Trainer: no HIP device visible; pass device='cpu' explicitly for the torch reference mode")
+            device = "cuda"
         self.net = TorchResNetRNN(weights, n_layers, n_layers_res, device=device, dtype=dtype)
         self.opt = TFOptimizer(self.net.trainable(), optimizer_choice, learning_rate)
         if optimizer_state:

@@ -96,3 +96,13 @@ def test_dropout_only_on_outputs_is_seeded():
     b = Trainer(w, 1, 1, "RMSProp", 1e-3, keep_prob=0.8, device="cpu", seed=7).train_step(x, y)
     c = Trainer(w, 1, 1, "RMSProp", 1e-3, keep_prob=1.0, device="cpu", seed=7).train_step(x, y)
     assert a == b and a != c
+
+
+def test_trainer_has_no_silent_cpu_fallback():
+    """Without a HIP device the default Trainer refuses to run; the torch-CPU mode is opt-in (device='cpu')."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    w = oracle.random_weights(seed=1, n_layers=1, n_layers_res=1)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Trainer(w, 1, 1, "Adam", 1e-3, keep_prob=1.0)
