@@ -1012,6 +1012,8 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_train_fwd_kernel<128>, gru_pack_floats(128) * 4);
         optin((const void*)gru_train_bwd_kernel<32>, gtb_pack_floats(32) * 4);
         optin((const void*)gru_train_bwd_kernel<128>, gtb_pack_floats(128) * 4);
+        optin((const void*)res_train_fwd_kernel, RT_FWD_LDS_BYTES);
+        optin((const void*)res_train_bwd_kernel, RT_BWD_LDS_BYTES);
         optin((const void*)gru_layer_bf16_kernel<32, false, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<32, true, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<128, false, 1>, gb_pack_bytes(128, 1));
@@ -1534,13 +1536,8 @@ extern "C" int cf_res_train_forward(cf_model* m, int32_t n_blocks, const float* 
     int rc = res_train_ok(m, n_blocks);
     if (rc != CF_OK) return rc;
     HIP_TRY(hipSetDevice(m->device));
-    static bool opted = false;
-    if (!opted) {
-        HIP_TRY(hipFuncSetAttribute((const void*)res_train_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RT_POS * 32 * 4));
-        opted = true;
-    }
     const int n_wg = (int)((n_windows + RT_WIN - 1) / RT_WIN);
-    hipLaunchKernelGGL(res_train_fwd_kernel, dim3(n_wg), dim3(RT_THREADS), 4 * RT_POS * 32 * 4, reinterpret_cast<hipStream_t>(stream), x, params,
+    hipLaunchKernelGGL(res_train_fwd_kernel, dim3(n_wg), dim3(RT_THREADS), RT_FWD_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), x, params,
                        z_stash, out, rt_make_layout(n_blocks), (int)n_windows, n_blocks, m->hp.bn_epsilon);
     HIP_TRY(hipGetLastError());
     return CF_OK;
@@ -1556,12 +1553,7 @@ extern "C" int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float*
     if (workspace_floats < cf_res_train_workspace_floats(n_blocks, n_windows))
         return fail(CF_ERR_INVALID, "cf_res_train_backward: workspace too small (see cf_res_train_workspace_floats)");
     HIP_TRY(hipSetDevice(m->device));
-    const int lds_bytes = (5 * RT_POS * 32 + 3 * 32 * 32 + 96) * 4;
-    static bool opted = false;
-    if (!opted) {
-        HIP_TRY(hipFuncSetAttribute((const void*)res_train_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        opted = true;
-    }
+    const int lds_bytes = RT_BWD_LDS_BYTES;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const rt_layout L = rt_make_layout(n_blocks);
     const int n_wg = (int)((n_windows + RT_WIN - 1) / RT_WIN);

@@ -20,6 +20,8 @@
 #define RT_THREADS 256
 #define RT_PG (RT_THREADS / 32)
 #define RT_MAX_UNITS 16
+#define RT_FWD_LDS_BYTES (4 * RT_POS * 32 * 4)                          // block input, o1, o2, shortcut
+#define RT_BWD_LDS_BYTES ((5 * RT_POS * 32 + 3 * 32 * 32 + 96) * 4)     // + gradient buffers and the reduction scratch
 
 struct rt_layout { int off[RT_MAX_UNITS + 1]; };
 
