@@ -572,18 +572,43 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
 // (`ends`, exclusive) through an atomic counter.  Padding labels are 0, so runs never cross reads;
 // after sorting both lists ascending on the host the k-th start pairs with the k-th end.
 // ------------------------------------------------------------------------------------------
+#define CF_SPANS_PER_THREAD 16
 __global__ __launch_bounds__(256) void spans_kernel(const uint8_t* __restrict__ labels, int64_t total, int64_t max_runs,
                                                     int64_t* __restrict__ starts, int64_t* __restrict__ ends,
                                                     unsigned long long* __restrict__ counts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total || !labels[i]) return;
-    if (i == 0 || !labels[i - 1]) {
-        const unsigned long long k = atomicAdd(&counts[0], 1ull);
-        if ((int64_t)k < max_runs) starts[k] = i;
+    // A workgroup scans 256 * CF_SPANS_PER_THREAD samples, reserves room for all its boundaries with ONE global atomic per
+    // list (slots inside the reservation come from LDS counters), then writes them.
+    __shared__ unsigned n_loc[2];
+    __shared__ unsigned long long base[2];
+    if (threadIdx.x < 2) n_loc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * 256 * CF_SPANS_PER_THREAD + threadIdx.x;
+    unsigned ms = 0, me = 0;                               // bit j: sample i0 + 256 j starts / ends a run
+#pragma unroll
+    for (int j = 0; j < CF_SPANS_PER_THREAD; ++j) {
+        const int64_t i = i0 + (int64_t)j * 256;
+        if (i < total && labels[i]) {
+            if (i == 0 || !labels[i - 1]) ms |= 1u << j;
+            if (i == total - 1 || !labels[i + 1]) me |= 1u << j;
+        }
     }
-    if (i == total - 1 || !labels[i + 1]) {
-        const unsigned long long k = atomicAdd(&counts[1], 1ull);
-        if ((int64_t)k < max_runs) ends[k] = i + 1;
+    unsigned os = 0, oe = 0;
+    if (ms) os = atomicAdd(&n_loc[0], (unsigned)__popc(ms));
+    if (me) oe = atomicAdd(&n_loc[1], (unsigned)__popc(me));
+    __syncthreads();
+    if (threadIdx.x < 2 && n_loc[threadIdx.x]) base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)n_loc[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CF_SPANS_PER_THREAD; ++j) {
+        const int64_t i = i0 + (int64_t)j * 256;
+        if (ms & (1u << j)) {
+            const unsigned long long k = base[0] + os++;
+            if ((int64_t)k < max_runs) starts[k] = i;
+        }
+        if (me & (1u << j)) {
+            const unsigned long long k = base[1] + oe++;
+            if ((int64_t)k < max_runs) ends[k] = i + 1;
+        }
     }
 }
 
@@ -1330,7 +1355,8 @@ extern "C" int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_sample
     HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(uint64_t), s));
     if (total_samples == 0) return CF_OK;
     if (!labels || (max_runs > 0 && (!starts || !ends))) return fail(CF_ERR_INVALID, "cf_spans: null buffer");
-    hipLaunchKernelGGL(spans_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, labels, total_samples, max_runs,
+    const int64_t per_wg = 256 * CF_SPANS_PER_THREAD;
+    hipLaunchKernelGGL(spans_kernel, dim3((unsigned)((total_samples + per_wg - 1) / per_wg)), dim3(256), 0, s, labels, total_samples, max_runs,
                        starts, ends, reinterpret_cast<unsigned long long*>(counts));
     HIP_TRY(hipGetLastError());
     return CF_OK;

@@ -3,8 +3,9 @@
 One batch = many reads packed back to back.  Per batch the device runs
 ``cf_normalize -> cf_infer -> cf_postprocess -> cf_spans``; only 2 B/sample go up and two short
 run-boundary lists come down.  Batches are double-buffered: the H2D copy of batch k+1 (copy stream,
-pinned staging) overlaps the kernels of batch k (compute stream), and the host-side span assembly of
-batch k-1 overlaps both.  This is the "secondary" (PCIe-inclusive) rate of SURVEY.md 8d; it is never
+pinned staging) overlaps the kernels of batch k (compute stream); the run lists of batch k go down on a
+third stream into pinned buffers as soon as its cf_spans is done (never queued behind batch k+1's kernels),
+and the host-side span assembly of batch k-1 overlaps all of it.  This is the "secondary" (PCIe-inclusive) rate of SURVEY.md 8d; it is never
 bench.py's ``value``.
 """
 from __future__ import annotations
@@ -19,7 +20,8 @@ from .infer import WINDOW_SIZE, padding_size_for
 
 
 class _Ticket(object):
-    __slots__ = ("lengths", "s_off", "starts", "ends", "counts", "counts_h", "done", "max_runs", "labels", "keep")
+    __slots__ = ("lengths", "s_off", "starts", "ends", "counts", "starts_h", "ends_h", "counts_h", "done", "max_runs", "labels",
+                 "keep")
 
 
 class ReadPipeline(object):
@@ -32,6 +34,9 @@ class ReadPipeline(object):
         self.min_run = int(min_run)
         self.compute = torch.cuda.Stream(self.dev)
         self.copy = torch.cuda.Stream(self.dev)
+        self.down = torch.cuda.Stream(self.dev)
+        self.out = [None, None]                                  # pinned (starts, ends, counts) per in-flight slot, grown on demand
+        self.inflight = [None, None]
         self.cap = int(max_samples_per_batch)
         # two pinned staging buffers (double buffering)
         self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(2)]
@@ -51,6 +56,8 @@ class ReadPipeline(object):
         win_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
         np.cumsum(n_win, out=win_off[1:])
         slot = self.k & 1
+        if self.inflight[slot] is not None:
+            raise RuntimeError("ReadPipeline: at most two batches in flight; collect() the oldest ticket first")
         self.k += 1
         self.stage_free[slot].synchronize()                     # previous H2D out of this staging buffer is done
         host = self.stage[slot].numpy()
@@ -63,29 +70,44 @@ class ReadPipeline(object):
             d_soff = torch.from_numpy(win_off * WINDOW_SIZE).to(self.dev, non_blocking=True)
             d_len = torch.from_numpy(lengths).to(self.dev, non_blocking=True)
             self.stage_free[slot].record(self.copy)
+            # normalisation rides on the copy stream: it overlaps the previous batch's biGRU kernels (which leave
+            # wave slots and 15 KiB of LDS free on every CU) instead of delaying this batch's
+            n_windows = int(win_off[-1])
+            x = torch.empty(n_windows, WINDOW_SIZE, dtype=torch.float32, device=self.dev)
+            self.eng.normalize_device(d_dac, d_doff, d_woff, out=x, stream=self.copy)
             copied = torch.cuda.Event()
             copied.record(self.copy)
         t = _Ticket()
-        with torch.cuda.stream(self.compute):
+        with torch.cuda.stream(self.compute):                    # the compute stream only ever holds the forward pass
             self.compute.wait_event(copied)
-            n_windows = int(win_off[-1])
-            x = torch.empty(n_windows, WINDOW_SIZE, dtype=torch.float32, device=self.dev)
-            self.eng.normalize_device(d_dac, d_doff, d_woff, out=x, stream=self.compute)
             probs = self.eng.infer_device(x, stream=self.compute)
+            infer_done = torch.cuda.Event()
+            infer_done.record(self.compute)
+        with torch.cuda.stream(self.down):                       # post-processing + D2H overlap the next batch's forward pass
+            self.down.wait_event(infer_done)
             labels = self.eng.postprocess_device(probs, d_soff, d_len, threshold=self.threshold, min_run=self.min_run,
-                                                 stream=self.compute)
+                                                 stream=self.down)
             max_runs = n_windows * WINDOW_SIZE // self.min_run + 16
             t.starts = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
             t.ends = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
             t.counts = torch.empty(2, dtype=torch.int64, device=self.dev)
             N.check(self.eng._lib.cf_spans(self.eng._handle, C.c_void_p(labels.data_ptr()), int(labels.numel()), max_runs,
                                            C.c_void_p(t.starts.data_ptr()), C.c_void_p(t.ends.data_ptr()),
-                                           C.c_void_p(t.counts.data_ptr()), C.c_void_p(self.compute.cuda_stream)))
-            t.counts_h = t.counts.to("cpu", non_blocking=True)
+                                           C.c_void_p(t.counts.data_ptr()), C.c_void_p(self.down.cuda_stream)))
+        if self.out[slot] is None or self.out[slot][0].numel() < max_runs:
+            self.out[slot] = (torch.empty(max_runs, dtype=torch.int64, pin_memory=True),
+                              torch.empty(max_runs, dtype=torch.int64, pin_memory=True),
+                              torch.empty(2, dtype=torch.int64, pin_memory=True))
+        t.starts_h, t.ends_h, t.counts_h = self.out[slot]
+        with torch.cuda.stream(self.down):                       # D2H of the (unsorted) run lists, whole capacity: ~1 MB
+            t.starts_h[:max_runs].copy_(t.starts, non_blocking=True)
+            t.ends_h[:max_runs].copy_(t.ends, non_blocking=True)
+            t.counts_h.copy_(t.counts, non_blocking=True)
             t.done = torch.cuda.Event()
-            t.done.record(self.compute)
+            t.done.record(self.down)
         t.lengths, t.s_off, t.max_runs, t.labels = lengths, win_off * WINDOW_SIZE, max_runs, labels
-        t.keep = (d_dac, d_doff, d_woff, d_soff, d_len, x, probs)   # keep device buffers alive until collected
+        t.keep = (d_dac, d_doff, d_woff, d_soff, d_len, x, probs, slot)   # keep device buffers alive until collected
+        self.inflight[slot] = t
         return t
 
     def collect(self, t, as_lists=True):
@@ -97,10 +119,11 @@ class ReadPipeline(object):
         n_s, n_e = (int(v) for v in t.counts_h.tolist())
         if n_s != n_e or n_s > t.max_runs:
             raise RuntimeError("cf_spans returned %d starts / %d ends (capacity %d)" % (n_s, n_e, t.max_runs))
-        with self.torch.cuda.stream(self.compute):
-            starts = np.sort(t.starts[:n_s].cpu().numpy())
-            ends = np.sort(t.ends[:n_e].cpu().numpy())
+        self.inflight[t.keep[-1]] = None
+        starts = np.sort(t.starts_h[:n_s].numpy())               # np.sort copies out of the pinned slot
+        ends = np.sort(t.ends_h[:n_e].numpy())
         t.keep = None
+        t.starts = t.ends = t.counts = None
         if not as_lists:
             read_of = np.searchsorted(t.s_off, starts, side="right") - 1
             base = t.s_off[read_of]
