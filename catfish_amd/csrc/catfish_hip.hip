@@ -71,6 +71,23 @@ __device__ __forceinline__ float cf_sigmoid_pre(float a) {   // a = -x * log2(e)
 __device__ __forceinline__ float cf_tanh_pre(float a) {      // a = 2 * x * log2(e)
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)), 1.0f);
 }
+// two elements at a time: the "+ 1" and the tanh fma become packed-fp32 instructions (v_pk_add_f32 / v_pk_fma_f32)
+__device__ __forceinline__ f32x2 cf_sigmoid_pre2(f32x2 a) {
+    f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    e = e + (f32x2){1.0f, 1.0f};
+    return (f32x2){__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+__device__ __forceinline__ f32x2 cf_tanh_pre2(f32x2 a) {
+    return __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, cf_sigmoid_pre2(a), (f32x2){1.0f, 1.0f});
+}
+__device__ __forceinline__ f32x4 cf_sigmoid_pre4(f32x4 a) {
+    f32x4 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), __builtin_amdgcn_exp2f(a.z), __builtin_amdgcn_exp2f(a.w)};
+    e = e + (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+    return (f32x4){__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y), __builtin_amdgcn_rcpf(e.z), __builtin_amdgcn_rcpf(e.w)};
+}
+__device__ __forceinline__ f32x4 cf_tanh_pre4(f32x4 a) {
+    return __builtin_elementwise_fma((f32x4){-2.0f, -2.0f, -2.0f, -2.0f}, cf_sigmoid_pre4(a), (f32x4){1.0f, 1.0f, 1.0f, 1.0f});
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     f32x4 o;
     o.x = fmaxf(v.x, 0.f); o.y = fmaxf(v.y, 0.f); o.z = fmaxf(v.z, 0.f); o.w = fmaxf(v.w, 0.f);
@@ -316,13 +333,10 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             f32x4 rh[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (CF_ABLATE & 1) { rh[m][r] = acc[m][r] * 0.001f; continue; }
-                    const float rv = cf_sigmoid_pre(acc[m][r]);
-                    rh[m][r] = rv * h[m][r];
-                    if constexpr (STASH) acc[m][r] = rv;
-                }
+                if (CF_ABLATE & 1) { rh[m] = acc[m] * 0.001f; continue; }
+                const f32x4 rv = cf_sigmoid_pre4(acc[m]);            // packed-fp32 "+ 1" and products, same rounding as scalar
+                rh[m] = rv * h[m];
+                if constexpr (STASH) acc[m] = rv;
             }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
@@ -339,14 +353,11 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             // h' = u*h + (1-u)*c                                  (gru_cell/mul_1, sub, mul_2, add)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (CF_ABLATE & 1) { h[m][r] = acc[4 + m][r] * 0.001f + acc[8 + m][r] * 0.001f; continue; }
-                    const float u = cf_sigmoid_pre(acc[4 + m][r]);
-                    const float c = cf_tanh_pre(acc[8 + m][r]);
-                    h[m][r] = fmaf(u, h[m][r] - c, c);
-                    if constexpr (STASH) { acc[4 + m][r] = u; acc[8 + m][r] = c; }
-                }
+                if (CF_ABLATE & 1) { h[m] = acc[4 + m] * 0.001f + acc[8 + m] * 0.001f; continue; }
+                const f32x4 u = cf_sigmoid_pre4(acc[4 + m]);
+                const f32x4 c = cf_tanh_pre4(acc[8 + m]);
+                h[m] = __builtin_elementwise_fma(u, h[m] - c, c);
+                if constexpr (STASH) { acc[4 + m] = u; acc[8 + m] = c; }
             }
             if constexpr (STASH) {
                 f32x4* sdst = S + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;

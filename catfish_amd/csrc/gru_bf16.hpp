@@ -163,9 +163,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
             for (int kb = 0; kb < 4; ++kb) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 8; j += 2) {
                     const int m = kb >> 1, i = 8 * (kb & 1) + j;
-                    v[j] = cf_sigmoid_pre(acc[m][i]) * h[m][i];
+                    const f32x2 rh = cf_sigmoid_pre2((f32x2){acc[m][i], acc[m][i + 1]}) * (f32x2){h[m][i], h[m][i + 1]};
+                    v[j] = rh.x;
+                    v[j + 1] = rh.y;
                 }
                 split8<NP>(v, rp[kb]);
             }
@@ -179,10 +181,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float u = cf_sigmoid_pre(acc[2 + m][i]);
-                    const float c = cf_tanh_pre(acc[4 + m][i]);
-                    h[m][i] = fmaf(u, h[m][i] - c, c);
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 u = cf_sigmoid_pre2((f32x2){acc[2 + m][i], acc[2 + m][i + 1]});
+                    const f32x2 c = cf_tanh_pre2((f32x2){acc[4 + m][i], acc[4 + m][i + 1]});
+                    const f32x2 hn = __builtin_elementwise_fma(u, (f32x2){h[m][i], h[m][i + 1]} - c, c);
+                    h[m][i] = hn.x;
+                    h[m][i + 1] = hn.y;
                 }
             }
 #pragma unroll
