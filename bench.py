@@ -71,8 +71,8 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pool-reads", type=int, default=2048, help="distinct synthetic reads per rank")
     ap.add_argument("--streams", type=int, default=0, help="scratch slots/internal streams per engine (0 = library default)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
