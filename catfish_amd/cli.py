@@ -74,18 +74,22 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
     os.makedirs(temp_dir_hp)          # raises if they exist, like the reference (:37-38)
     os.mkdir(temp_dir_nonhp)
 
-    t1 = datetime.datetime.now()
-    network_path = os.path.abspath(network_path)
-    model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint, device=device)
-    print("Loaded model in {}".format(datetime.datetime.now() - t1))
-
     input_dir = os.path.abspath(input_dir)
     input_files = os.listdir(input_dir)
+
+    t1 = datetime.datetime.now()
+    network_path = os.path.abspath(network_path)
+    # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
+    # tail instead of 8 % and the three layers go out as one dynamically scheduled launch.
+    max_windows = 131072 if len(input_files) > 400 else 32768
+    model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint, device=device,
+                                        max_windows_per_pass=max_windows)
+    print("Loaded model in {}".format(datetime.datetime.now() - t1))
 
     print("Checking for homopolymers in raw signal..")
     t2 = datetime.datetime.now()
     signals = [infer.load_raw("{}/{}".format(input_dir, f)) for f in input_files]
-    results = batching.infer_reads(model, signals)
+    results = batching.infer_reads(model, signals, max_windows=max_windows)
     for fast5_file, (hp_positions, len_read) in zip(input_files, results):
         if hp_positions != []:
             merged_positions = merge_positions(hp_positions, len_read, chunk_size)
