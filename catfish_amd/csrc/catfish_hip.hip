@@ -256,8 +256,12 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
     constexpr int DENSE = gru_dense_off(CIN);
     const int q = lane >> 4;
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;     // + (ks*3+g)*64
-    const f32x4* WG = WX + XN4;                                        // + (ks*2+g)*64
-    const f32x4* WC = WG + HG4;                                        // + ks*64
+    // The packed weights span up to 144 KiB but a ds_read immediate offset reaches 64 KiB: keep two more base
+    // pointers live (opaque offsets, or the compiler re-adds the constant in front of every far read: 32 v_add per step).
+    int far1 = 4096, far2 = 8192;
+    asm volatile("" : "+v"(far1), "+v"(far2));
+    const f32x4* WX1 = WX + far1;
+    const f32x4* WX2 = WX + far2;
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;  // + mo*4
     const f32x4* D4 = reinterpret_cast<const f32x4*>(lds + DENSE) + q; // + m*4
     {
@@ -279,10 +283,12 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             // k-steps of the whole step form one sequence p: x part [0, KSX), gate h part [KSX, KSX+16), candidate
             // h part [KSX+16, KSX+32); fragments are fetched PF k-steps ahead.
             constexpr int PF = CF_PREFETCH;
+            // element e (f32x4 units from WX) through the base pointer whose 16-bit ds_read offset reaches it
+            auto A = [&](int e) -> f32x4 { return e < 4096 ? WX[e] : (e < 8192 ? WX1[e - 4096] : WX2[e - 8192]); };
             auto loadA = [&](int p, f32x4 (&d)[3]) {
-                if (p < KSX) { d[0] = WX[(p * 3 + 0) * 64]; d[1] = WX[(p * 3 + 1) * 64]; d[2] = WX[(p * 3 + 2) * 64]; }
-                else if (p < KSX + 16) { d[0] = WG[((p - KSX) * 2 + 0) * 64]; d[1] = WG[((p - KSX) * 2 + 1) * 64]; }
-                else if (p < KSX + 32) { d[0] = WC[(p - KSX - 16) * 64]; }
+                if (p < KSX) { d[0] = A((p * 3 + 0) * 64); d[1] = A((p * 3 + 1) * 64); d[2] = A((p * 3 + 2) * 64); }
+                else if (p < KSX + 16) { d[0] = A(XN4 + ((p - KSX) * 2 + 0) * 64); d[1] = A(XN4 + ((p - KSX) * 2 + 1) * 64); }
+                else if (p < KSX + 32) { d[0] = A(XN4 + HG4 + (p - KSX - 16) * 64); }
             };
             f32x4 ac[3], an[3], a2[3];
             loadA(0, ac);
