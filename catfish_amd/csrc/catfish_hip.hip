@@ -80,6 +80,20 @@ __device__ __forceinline__ f32x2 cf_sigmoid_pre2(f32x2 a) {
 __device__ __forceinline__ f32x2 cf_tanh_pre2(f32x2 a) {
     return __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, cf_sigmoid_pre2(a), (f32x2){1.0f, 1.0f});
 }
+// LDS arrays larger than a ds_read immediate offset reaches (64 KiB): three base pointers kept live in registers.
+// The opaque offsets stop the compiler from folding them back into base + constant, which it would re-add in
+// front of every far read.  Index with compile-time constants (unrolled loops) so the selection folds away.
+template <typename T>
+struct far_lds {
+    static constexpr int N64K = 65536 / sizeof(T);
+    const T *b0, *b1, *b2;
+    __device__ __forceinline__ explicit far_lds(const T* base) {
+        int o1 = N64K, o2 = 2 * N64K;
+        asm volatile("" : "+v"(o1), "+v"(o2));
+        b0 = base; b1 = base + o1; b2 = base + o2;
+    }
+    __device__ __forceinline__ const T& operator[](int e) const { return e < N64K ? b0[e] : (e < 2 * N64K ? b1[e - N64K] : b2[e - 2 * N64K]); }
+};
 __device__ __forceinline__ f32x4 cf_sigmoid_pre4(f32x4 a) {
     f32x4 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y), __builtin_amdgcn_exp2f(a.z), __builtin_amdgcn_exp2f(a.w)};
     e = e + (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
@@ -256,12 +270,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
     constexpr int DENSE = gru_dense_off(CIN);
     const int q = lane >> 4;
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;     // + (ks*3+g)*64
-    // The packed weights span up to 144 KiB but a ds_read immediate offset reaches 64 KiB: keep two more base
-    // pointers live (opaque offsets, or the compiler re-adds the constant in front of every far read: 32 v_add per step).
-    int far1 = 4096, far2 = 8192;
-    asm volatile("" : "+v"(far1), "+v"(far2));
-    const f32x4* WX1 = WX + far1;
-    const f32x4* WX2 = WX + far2;
+    const far_lds<f32x4> WL(WX);      // the packed weights span up to 144 KiB (far_lds: 32 v_add per step less, 168 -> 122 VGPRs)
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;  // + mo*4
     const f32x4* D4 = reinterpret_cast<const f32x4*>(lds + DENSE) + q; // + m*4
     {
@@ -283,12 +292,10 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             // k-steps of the whole step form one sequence p: x part [0, KSX), gate h part [KSX, KSX+16), candidate
             // h part [KSX+16, KSX+32); fragments are fetched PF k-steps ahead.
             constexpr int PF = CF_PREFETCH;
-            // element e (f32x4 units from WX) through the base pointer whose 16-bit ds_read offset reaches it
-            auto A = [&](int e) -> f32x4 { return e < 4096 ? WX[e] : (e < 8192 ? WX1[e - 4096] : WX2[e - 8192]); };
             auto loadA = [&](int p, f32x4 (&d)[3]) {
-                if (p < KSX) { d[0] = A((p * 3 + 0) * 64); d[1] = A((p * 3 + 1) * 64); d[2] = A((p * 3 + 2) * 64); }
-                else if (p < KSX + 16) { d[0] = A(XN4 + ((p - KSX) * 2 + 0) * 64); d[1] = A(XN4 + ((p - KSX) * 2 + 1) * 64); }
-                else if (p < KSX + 32) { d[0] = A(XN4 + HG4 + (p - KSX - 16) * 64); }
+                if (p < KSX) { d[0] = WL[(p * 3 + 0) * 64]; d[1] = WL[(p * 3 + 1) * 64]; d[2] = WL[(p * 3 + 2) * 64]; }
+                else if (p < KSX + 16) { d[0] = WL[XN4 + ((p - KSX) * 2 + 0) * 64]; d[1] = WL[XN4 + ((p - KSX) * 2 + 1) * 64]; }
+                else if (p < KSX + 32) { d[0] = WL[XN4 + HG4 + (p - KSX - 16) * 64]; }
             };
             f32x4 ac[3], an[3], a2[3];
             loadA(0, ac);

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hh = lane >> 5;
     const bf16x8* WA = reinterpret_cast<const bf16x8*>(lds) + lane;                     // + (p*NP + part)*64
+    const far_lds<bf16x8> WAF(WA);
+#define CF_WA(e) (WAF[(e)])
     const f32x4* BI = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_bias_off(CIN, NP)) + hh * 4;
     const f32x4* DW = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_dense_off(CIN, NP)) + hh * 4;
 
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
 #pragma unroll
         for (int q = 0; q < DA; ++q)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) ar[q][p] = WA[(q * NP + p) * 64];
+            for (int p = 0; p < NP; ++p) ar[q][p] = CF_WA((q * NP + p) * 64);
 
         for (int s = 0; s < CF_T; ++s) {
             const int t = t0 + s * tstep;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_bf16_kernel(const char* __re
         bf16x8 a_[NP];                                                                     \
         _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) a_[pp] = ar[(p) % DA][pp];       \
         _Pragma("unroll") for (int pp = 0; pp < NP; ++pp)                                  \
-            ar[(p) % DA][pp] = WA[((((p) + DA) % NSEQ) * NP + pp) * 64];                   \
+            ar[(p) % DA][pp] = CF_WA(((((p) + DA) % NSEQ) * NP + pp) * 64);                \
         acc[mt] = prod<NP>(a_, bparts, acc[mt]);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }

@@ -24,7 +24,7 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
     const int q = lane >> 4;
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;
     const f32x4* WG = WX + XN4;
-    const f32x4* WC = WG + HG4;
+    const f32x4* WC = WG + HG4;       // (far_lds measured 1 % slower here: the step is latency-, not issue-bound)
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;
     f32x4* hx = reinterpret_cast<f32x4*>(xch) + lane;              // [4 M-tiles][64 lanes] f32x4: the state h
     f32x4* rx = hx + 4 * 64;                                        // r * h
@@ -192,8 +192,7 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
     constexpr int MX = CIN / 16;
     constexpr int NXW = MX > W ? (MX - W + 3) / 4 : 0;          // x-row tiles of this wave: W, W+4, ...
     constexpr int CF2 = 16 * (MI / 2) * 64;                     // candidate region in f32x2 units
-    const f32x2* WCt = reinterpret_cast<const f32x2*>(lds) + lane;
-    const f32x2* WGt = WCt + CF2;
+    const far_lds<f32x2> WT(reinterpret_cast<const f32x2*>(lds) + lane);      // candidate region | gate region
     f32x4* XC = reinterpret_cast<f32x4*>(xch) + lane;           // da_c tiles [4][64]
     f32x4* XR = XC + 4 * 64;                                    // da_r
     f32x4* XU = XR + 4 * 64;                                    // da_u
@@ -229,12 +228,12 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const float b = dacf[ks >> 2][ks & 3];
-            drh = MFMA16(WCt[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, drh);
+            drh = MFMA16(WT[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, drh);
 #pragma unroll
             for (int i = 0; i < NXW; ++i) {
                 constexpr int dummy = 0; (void)dummy;
                 const int xt = W + 4 * i;
-                dx[i] = MFMA16(WCt[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
+                dx[i] = MFMA16(WT[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -248,11 +247,11 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) {
             const float b = dag[ks >> 2][ks & 3];
-            dhg = MFMA16(WGt[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, dhg);
+            dhg = MFMA16(WT[CF2 + (ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, dhg);
 #pragma unroll
             for (int i = 0; i < NXW; ++i) {
                 const int xt = W + 4 * i;
-                dx[i] = MFMA16(WGt[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
+                dx[i] = MFMA16(WT[CF2 + (ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -63,8 +63,7 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const f32x2* WC = reinterpret_cast<const f32x2*>(lds) + lane;      // + (ks*(MI/2) + mi2)*64
-    const f32x2* WGt = WC + CF2;
+    const far_lds<f32x2> WT(reinterpret_cast<const f32x2*>(lds) + lane);   // candidate region + (ks*(MI/2) + mi2)*64 | gate region
 
     for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves) {
         f32x4 dhc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // gradient carried to the previous step
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
                 const float b = dac[ks >> 2][ks & 3];
 #pragma unroll
                 for (int mi2 = 0; mi2 < MI / 2; ++mi2) {
-                    const f32x2 a = WC[(ks * (MI / 2) + mi2) * 64];
+                    const f32x2 a = WT[(ks * (MI / 2) + mi2) * 64];
                     const int m0 = 2 * mi2, m1 = 2 * mi2 + 1;
                     if (m0 < MX) dx[m0] = MFMA16(a.x, b, dx[m0]); else drh[m0 - MX] = MFMA16(a.x, b, drh[m0 - MX]);
                     if (m1 < MX) dx[m1] = MFMA16(a.y, b, dx[m1]); else drh[m1 - MX] = MFMA16(a.y, b, drh[m1 - MX]);
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
                 const float b = dag[ks >> 2][ks & 3];
 #pragma unroll
                 for (int mi2 = 0; mi2 < MI / 2; ++mi2) {
-                    const f32x2 a = WGt[(ks * (MI / 2) + mi2) * 64];
+                    const f32x2 a = WT[CF2 + (ks * (MI / 2) + mi2) * 64];
                     const int m0 = 2 * mi2, m1 = 2 * mi2 + 1;
                     if (m0 < MX) dx[m0] = MFMA16(a.x, b, dx[m0]); else dhg[m0 - MX] = MFMA16(a.x, b, dhg[m0 - MX]);
                     if (m1 < MX) dx[m1] = MFMA16(a.y, b, dx[m1]); else dhg[m1 - MX] = MFMA16(a.y, b, dhg[m1 - MX]);
