@@ -258,6 +258,19 @@ __device__ __forceinline__ void gru_stage_weights(float* lds, const float* __res
 // One tile (16 windows) of one direction of one layer: the whole 35-step recurrence.
 // STASH (training forward): also write the activated gates r, u and the candidate c of every step to
 // S[tile][t][dir][12][lane] (r = 0..3, u = 4..7, c = 8..11) for the backward pass.
+// One k-step region: the A-fragment reads of the NEXT k-step go out before this k-step's MFMAs (left alone the
+// scheduler sinks them behind most of the MFMAs, which leaves ~100 cycles between a read and its first use).
+#ifndef CF_SCHED_DS_FIRST
+#define CF_SCHED_DS_FIRST 1
+#endif
+#if CF_SCHED_DS_FIRST
+#define CF_KSTEP_SCHED(nds, nmfma)                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, nds, 0);         \
+    __builtin_amdgcn_sched_group_barrier(0x008, nmfma, 0);       \
+    __builtin_amdgcn_sched_barrier(0)
+#else
+#define CF_KSTEP_SCHED(nds, nmfma) __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int CIN, bool LAST, bool STASH = false>
 __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, int tile, const f32x4* __restrict__ X,
                                          f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
@@ -286,7 +299,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
             const int t = dir ? (CF_T - 1 - s) : s;    // bw = time-reversed sequence (ReverseV2)
             f32x4 acc[12];
 #pragma unroll
-            for (int mo = 0; mo < 12; ++mo) acc[mo] = B4[mo * 4];
+            for (int mo = 0; mo < 12; ++mo) acc[mo] = B4[mo * 4];     // (bias held in registers as the first C operand: measured neutral)
             // The A fragments are software-pipelined one k-step ahead by hand; the
             // sched_barriers keep hipcc from hoisting hundreds of ds_reads (it spills otherwise).
             // k-steps of the whole step form one sequence p: x part [0, KSX), gate h part [KSX, KSX+16), candidate
@@ -312,7 +325,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                     acc[4 * g + 2] = MFMA16(ac[g].z, b, acc[4 * g + 2]);
                     acc[4 * g + 3] = MFMA16(ac[g].w, b, acc[4 * g + 3]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                CF_KSTEP_SCHED(3, 12);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) { ac[g] = an[g]; if (PF == 2) an[g] = a2[g]; }
             }
@@ -337,7 +350,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                     acc[4 * g + 2] = MFMA16(ac[g].z, b, acc[4 * g + 2]);
                     acc[4 * g + 3] = MFMA16(ac[g].w, b, acc[4 * g + 3]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                CF_KSTEP_SCHED(2, 8);
                 ac[0] = an[0]; ac[1] = an[1];
                 if (PF == 2) { an[0] = a2[0]; an[1] = a2[1]; }
             }
@@ -359,7 +372,7 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                 acc[9] = MFMA16(ac[0].y, b, acc[9]);
                 acc[10] = MFMA16(ac[0].z, b, acc[10]);
                 acc[11] = MFMA16(ac[0].w, b, acc[11]);
-                __builtin_amdgcn_sched_barrier(0);
+                CF_KSTEP_SCHED(1, 4);
                 ac[0] = an[0];
                 if (PF == 2) an[0] = a2[0];
             }
