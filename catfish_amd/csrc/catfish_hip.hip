@@ -428,7 +428,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves)
+    // Every workgroup takes an equal contiguous share of the tiles (+-1) and deals it round-robin to its waves, so that all
+    // SIMDs of the chip end within one tile of each other whatever the wave count.
+    const int t0 = (int)((int64_t)blockIdx.x * n_tiles / gridDim.x);
+    const int t1 = (int)((int64_t)(blockIdx.x + 1) * n_tiles / gridDim.x);
+    for (int tile = t0 + wave; tile < t1; tile += nwaves)
         gru_tile<CIN, LAST>(lds, lane, dir, tile, X, Y, P, n_tiles);
 }
 
@@ -1133,7 +1137,9 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
         HIP_TRY(hipGetLastError());
         return prof_end(m, s, pi);
     }
-    const int waves = (CF_ABLATE & 4) ? 4 : pick_waves(2 * n_tiles, m->n_cu);
+    static const int waves_env = getenv("CATFISH_WAVES") ? atoi(getenv("CATFISH_WAVES")) : 0;     // A/B knob for tools/
+    // (12 waves = 3 per SIMD measured +0.3 % on the Cin = 128 layers and costs the Cin = 32 layer its second workgroup per CU)
+    const int waves = waves_env > 0 ? std::min(waves_env, 8) : ((CF_ABLATE & 4) ? 4 : pick_waves(2 * n_tiles, m->n_cu));
     const int groups = (n_tiles + waves - 1) / waves;             // one workgroup pass = one tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;            // persistent: half the CUs per direction
     constexpr int lds_bytes = gru_pack_floats(CIN) * 4;
