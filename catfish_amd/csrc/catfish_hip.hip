@@ -1538,8 +1538,9 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
 }
 
 static int wgrad_pairs_per_wg(int n_pairs, int n_cu) {
-    // enough chunks to cover the chip once per direction, at least 4 pairs each so the partial sums stay small
-    return std::max(4, (n_pairs + n_cu - 1) / n_cu);
+    // two directions x n_chunks workgroups should cover the chip about once; at least 8 pairs each keeps the
+    // partial sums (148 KiB per workgroup) well below the traffic of the operands themselves
+    return std::max(8, (2 * n_pairs + n_cu - 1) / n_cu);
 }
 
 extern "C" int64_t cf_gru_wgrad_workspace_floats(cf_model* m, int32_t cin, int64_t n_windows) {
@@ -1576,7 +1577,7 @@ extern "C" int cf_gru_train_wgrad(cf_model* m, int32_t cin, const float* x_frag,
                            workspace, n_tiles, ppw);
     HIP_TRY(hipGetLastError());
     const int per = gwg_partial_floats(cin);
-    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((per + 255) / 256, 2), dim3(256), 0, s, workspace, grads, gwg_rows(cin), n_chunks);
+    hipLaunchKernelGGL(gru_wgrad_reduce_kernel, dim3((per + 63) / 64, 2), dim3(256), 0, s, workspace, grads, gwg_rows(cin), n_chunks);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }
@@ -1630,7 +1631,7 @@ extern "C" int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float*
                        (int)n_windows, n_blocks, m->hp.bn_epsilon);
     HIP_TRY(hipGetLastError());
     const int nf = L.off[4 * n_blocks];
-    hipLaunchKernelGGL(res_train_reduce_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, workspace, grads, nf, n_wg);
+    hipLaunchKernelGGL(res_train_reduce_kernel, dim3((nf + 63) / 64), dim3(256), 0, s, workspace, grads, nf, n_wg);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }

@@ -111,14 +111,35 @@ __global__ __launch_bounds__(CF_WGRAD_WAVES * 64) void gru_wgrad_kernel(const f3
     if (lane < 16) out[ROWS * 192 + 16 * wave + lane] = bsum;
 }
 
+// Sum of `n_parts` partial vectors (element e of part c at P[c * stride + e]) in a FIXED order: a 256-thread block owns 64
+// consecutive elements, thread group g = tid >> 6 adds parts g, g + 4, ... with four independent accumulators, the four
+// group sums are combined 0..3 through LDS.  Returns the total to the threads of group 0 (others get 0).
+__device__ __forceinline__ float cf_reduce_parts(const float* __restrict__ P, size_t stride, int n_parts, int e, bool valid) {
+    __shared__ float red[4][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (valid) {
+        int c = g;
+        for (; c + 12 < n_parts; c += 16) {
+            a0 += P[(size_t)c * stride + e];
+            a1 += P[(size_t)(c + 4) * stride + e];
+            a2 += P[(size_t)(c + 8) * stride + e];
+            a3 += P[(size_t)(c + 12) * stride + e];
+        }
+        for (; c < n_parts; c += 4) a0 += P[(size_t)c * stride + e];
+    }
+    red[g][l] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    return g == 0 ? (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]) : 0.f;
+}
+
 // out[dir] = wg [rows][128] | bg [128] | wc [rows][64] | bc [64]   (TensorFlow variable layouts)
 __global__ __launch_bounds__(256) void gru_wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, int rows, int n_chunks) {
     const int per = (rows + 1) * 192;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dir = blockIdx.y;
-    if (e >= per) return;
-    float sum = 0.f;
-    for (int c = 0; c < n_chunks; ++c) sum += P[((size_t)c * 2 + dir) * per + e];
+    const float sum = cf_reduce_parts(P + (size_t)dir * per, (size_t)2 * per, n_chunks, e, e < per);
+    if (e >= per || threadIdx.x >= 64) return;
     const int row = e / 192, col = e - row * 192;
     const int bg_off = rows * 128, wc_off = bg_off + 128, bc_off = wc_off + rows * 64;
     int dst;

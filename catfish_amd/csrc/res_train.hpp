@@ -315,9 +315,7 @@ __global__ __launch_bounds__(RT_THREADS) void res_train_bwd_kernel(const float* 
 }
 
 __global__ __launch_bounds__(256) void res_train_reduce_kernel(const float* __restrict__ P, float* __restrict__ grads, int n_floats, int n_wg) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_floats) return;
-    float s = 0.f;
-    for (int w = 0; w < n_wg; ++w) s += P[(size_t)w * n_floats + i];
-    grads[i] = s;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = cf_reduce_parts(P, (size_t)n_floats, n_wg, i, i < n_floats);      // fixed summation order (gru_wgrad.hpp)
+    if (i < n_floats && threadIdx.x < 64) grads[i] = s;
 }
