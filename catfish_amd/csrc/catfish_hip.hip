@@ -1126,7 +1126,8 @@ static int pick_waves(int n_tile_tasks, int n_cu) {
 template <int CIN, bool LAST>
 static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
     static const int coop_env = getenv("CATFISH_COOP") ? atoi(getenv("CATFISH_COOP")) : -1;      // A/B knob for tools/
-    const bool coop = coop_env >= 0 ? coop_env != 0 : 2 * n_tiles <= m->n_cu;                     // latency mode: every tile gets a CU
+    // latency mode: up to two rounds of one (tile, direction) per CU (0.35 units each) beat one wave per tile (1 unit)
+    const bool coop = coop_env >= 0 ? coop_env != 0 : n_tiles <= m->n_cu;
     if (coop && !(CF_ABLATE & 4)) {
         size_t pi = 0;
         int rc = prof_begin(m, slot, s, &pi);
@@ -1472,7 +1473,7 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
-    if (2 * n_tiles <= m->n_cu) {            // small batch: four waves per tile (latency mode)
+    if (n_tiles <= m->n_cu) {                // small batch: four waves per tile (latency mode), up to two rounds
         const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
         if (cin == CF_C)
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
@@ -1506,7 +1507,7 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
-    if (2 * n_tiles <= m->n_cu) {            // small batch: four waves per tile (latency mode)
+    if (n_tiles <= m->n_cu) {                // small batch: four waves per tile (latency mode), up to two rounds
         const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
         if (cin == CF_C)
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
