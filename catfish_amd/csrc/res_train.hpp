@@ -15,7 +15,7 @@
 // moving_mean[32] | moving_variance[32]  (TensorFlow layouts), units back to back; cin = 1 for units 0 and 1.
 #pragma once
 
-#define RT_WIN 4
+#define RT_WIN 2
 #define RT_POS (RT_WIN * CF_T)
 #define RT_THREADS 256
 #define RT_PG (RT_THREADS / 32)
