@@ -139,7 +139,9 @@ __host__ __device__ constexpr int frag_feature(int ks, int q) { return 16 * (ks 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: residual block (resnet_class.py:44-82), BN folded into the convs.
 // One wave = one tile of 16 windows, streamed over t with a one-step lookahead
-// for the k=3 conv (zero padding at both window edges).
+// for the k=3 conv (zero padding at both window edges).  Small calls (latency mode) split a tile's 35
+// positions into `t_chunks` chunks, one wave each: a chunk starts one position early to rebuild the k=3
+// conv's left neighbour, otherwise the stream is the same.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void unit_mma(const float* __restrict__ unit, int lane, const f32x4 (&in)[2], f32x4 (&acc)[2]) {
     const f32x2* u2 = reinterpret_cast<const f32x2*>(unit) + lane;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
                                                         const float* __restrict__ x_nat,   // FIRST: [n_windows, 35]
                                                         const f32x4* __restrict__ x_frag,  // !FIRST: [tile][t][2][lane]
                                                         f32x4* __restrict__ y_frag,        // [tile][t][2][lane]
-                                                        int64_t n_windows, int n_tiles) {
+                                                        int64_t n_windows, int n_tiles, int t_chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = res_pack_floats(FIRST);
     constexpr int VEC0 = res_units(FIRST) * 1024;
@@ -177,7 +179,11 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
         return *reinterpret_cast<const f32x4*>(lds + VEC0 + v * 32 + mo * 16 + q * 4);
     };
 
-    for (int tile = blockIdx.x * waves_per_block + wave; tile < n_tiles; tile += gridDim.x * waves_per_block) {
+    const int chunk_len = (CF_T + t_chunks - 1) / t_chunks;
+    for (int task = blockIdx.x * waves_per_block + wave; task < n_tiles * t_chunks; task += gridDim.x * waves_per_block) {
+        const int tile = task / t_chunks;
+        const int p0 = (task - tile * t_chunks) * chunk_len;          // this wave writes positions [p0, p1)
+        const int p1 = min(p0 + chunk_len, CF_T);
         f32x4 w_sc[2], b_sc[2], w_f[2], b_f[2];
         if constexpr (FIRST) {
             // stage the tile's raw samples: 16 windows x 35 = 560 contiguous floats
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
         f32x4 o1_pp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         f32x4 o1_p[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         f32x4 sc_p[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int i = 0; i <= CF_T; ++i) {
+        for (int i = p0 > 0 ? p0 - 1 : 0; i <= p1; ++i) {
             f32x4 o1_c[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
             f32x4 sc_c[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
             if (i < CF_T) {
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
                     o1_c[0] = relu4(acc[0]); o1_c[1] = relu4(acc[1]);
                 }
             }
-            if (i >= 1) {
+            if (i >= p0 + 1) {
                 constexpr int U3 = FIRST ? 0 : 2;      // first k=3 tap unit
                 constexpr int VB3 = FIRST ? 0 : 2;     // bias vector of the k=3 conv
                 f32x4 acc[2] = {vec(VB3, 0), vec(VB3, 1)};
@@ -1188,8 +1194,11 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     int rc;
     size_t pi = 0;
     // residual blocks
-    const int res_waves = pick_waves(n_tiles, m->n_cu * 2) > 4 ? 4 : pick_waves(n_tiles, m->n_cu * 2);
-    const int res_grid = std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
+    // latency mode (fp32): one workgroup per tile, four waves, each streaming a quarter of the 35 positions
+    const bool res_split = m->np == 0 && n_tiles <= m->n_cu;
+    const int res_chunks = res_split ? 4 : 1;
+    const int res_waves = res_split ? 4 : (pick_waves(n_tiles, m->n_cu * 2) > 4 ? 4 : pick_waves(n_tiles, m->n_cu * 2));
+    const int res_grid = res_split ? n_tiles : std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
     for (int b = 0; b < m->hp.n_layers_res; ++b) {
         float* dst = sl.d_a[b & 1];
         if (m->np > 0) {
@@ -1216,14 +1225,14 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
             }
         } else if (b == 0) {
             if ((rc = prof_begin(m, SLOT_RES_FIRST, s, &pi)) != CF_OK) return rc;
-            const int lds_bytes = (res_pack_floats(true) + 4 * CF_TILE * CF_T) * 4;
+            const int lds_bytes = (res_pack_floats(true) + res_waves * CF_TILE * CF_T) * 4;
             hipLaunchKernelGGL((res_block_kernel<true>), dim3(res_grid), dim3(res_waves * 64), lds_bytes, s, m->d_res[0], x,
-                               (const f32x4*)nullptr, reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
+                               (const f32x4*)nullptr, reinterpret_cast<f32x4*>(dst), n_windows, n_tiles, res_chunks);
         } else {
             if ((rc = prof_begin(m, SLOT_RES, s, &pi)) != CF_OK) return rc;
             const int lds_bytes = res_pack_floats(false) * 4;
             hipLaunchKernelGGL((res_block_kernel<false>), dim3(res_grid), dim3(res_waves * 64), lds_bytes, s, m->d_res[b], (const float*)nullptr,
-                               reinterpret_cast<const f32x4*>(sl.d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles);
+                               reinterpret_cast<const f32x4*>(sl.d_a[(b - 1) & 1]), reinterpret_cast<f32x4*>(dst), n_windows, n_tiles, res_chunks);
         }
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
