@@ -10,6 +10,9 @@
 
 template <int W>
 __device__ __forceinline__ float pick4(const f32x4& a) { return a[W]; }
+#ifndef CF_COOP_PF
+#define CF_COOP_PF 4        // A-fragment prefetch depth (k-steps) of the cooperative forward kernel
+#endif
 
 template <int CIN, bool LAST, int W, bool STASH = false>
 __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ X,
@@ -40,23 +43,38 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
 #pragma unroll
         for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
     }
+    // A fragments: this wave needs only component W of each packed f32x4 (its own M-tile), read as one dword.  With a
+    // single wave per SIMD nothing else hides the LDS latency, so the fragments of the whole step form ONE sequence
+    // p = 0 .. KSX+31 (x part: 3 per k-step, gate h part: 2, candidate h part: 1) fetched CF_COOP_PF k-steps ahead
+    // through a register ring; fetches of the next phase (and of the next step) run across the barriers.
+    constexpr int PF = CF_COOP_PF;
+    constexpr int NSEQ = KSX + 32;
+    static_assert(NSEQ % PF == 0, "the ring slot of a fragment must not change across the step boundary");
+    const float* WF = reinterpret_cast<const float*>(WX) + W;      // + element * 4 floats
+    float ring[PF][3];
+    auto fetch = [&](int p, float (&d)[3]) {                        // p is taken modulo the step's sequence
+        p = p % NSEQ;
+        if (p < KSX) { d[0] = WF[((p * 3 + 0) * 64) * 4]; d[1] = WF[((p * 3 + 1) * 64) * 4]; d[2] = WF[((p * 3 + 2) * 64) * 4]; }
+        else if (p < KSX + 16) { d[0] = WF[(XN4 + ((p - KSX) * 2 + 0) * 64) * 4]; d[1] = WF[(XN4 + ((p - KSX) * 2 + 1) * 64) * 4]; }
+        else { d[0] = WF[(XN4 + HG4 + (p - KSX - 16) * 64) * 4]; }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(p, ring[p]);
     for (int s = 0; s < CF_T; ++s) {
         const int t = dir ? (CF_T - 1 - s) : s;
         f32x4 hf[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) hf[m] = hx[m * 64];
         f32x4 ar = B4[(0 + W) * 4], au = B4[(4 + W) * 4], acnd = B4[(8 + W) * 4];
-        f32x4 c0 = WX[0], c1 = WX[64], c2 = WX[128], n0, n1, n2;
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
-            if (ks + 1 < KSX) { n0 = WX[((ks + 1) * 3 + 0) * 64]; n1 = WX[((ks + 1) * 3 + 1) * 64]; n2 = WX[((ks + 1) * 3 + 2) * 64]; }
-            else { n0 = WG[0]; n1 = WG[64]; }
+            const float a0 = ring[ks % PF][0], a1 = ring[ks % PF][1], a2 = ring[ks % PF][2];
+            fetch(ks + PF, ring[ks % PF]);
             const float b = xc[ks >> 2][ks & 3];
-            ar = MFMA16(pick4<W>(c0), b, ar);
-            au = MFMA16(pick4<W>(c1), b, au);
-            acnd = MFMA16(pick4<W>(c2), b, acnd);
+            ar = MFMA16(a0, b, ar);
+            au = MFMA16(a1, b, au);
+            acnd = MFMA16(a2, b, acnd);
             __builtin_amdgcn_sched_barrier(0);
-            c0 = n0; c1 = n1; c2 = n2;
         }
         {
             int tn = dir ? (t - 1) : (t + 1);
@@ -67,13 +85,13 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) { n0 = WG[((ks + 1) * 2 + 0) * 64]; n1 = WG[((ks + 1) * 2 + 1) * 64]; }
-            else { n0 = WC[0]; }
+            const int p = KSX + ks;
+            const float a0 = ring[p % PF][0], a1 = ring[p % PF][1];
+            fetch(p + PF, ring[p % PF]);
             const float b = hf[ks >> 2][ks & 3];
-            ar = MFMA16(pick4<W>(c0), b, ar);
-            au = MFMA16(pick4<W>(c1), b, au);
+            ar = MFMA16(a0, b, ar);
+            au = MFMA16(a1, b, au);
             __builtin_amdgcn_sched_barrier(0);
-            c0 = n0; c1 = n1;
         }
         f32x4 rh;
 #pragma unroll
@@ -85,11 +103,12 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
         for (int m = 0; m < 4; ++m) rf[m] = rx[m * 64];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) n0 = WC[(ks + 1) * 64];
+            const int p = KSX + 16 + ks;
+            const float a0 = ring[p % PF][0];
+            fetch(p + PF, ring[p % PF]);                            // wraps into the next step's x part
             const float b = rf[ks >> 2][ks & 3];
-            acnd = MFMA16(pick4<W>(c0), b, acnd);
+            acnd = MFMA16(a0, b, acnd);
             __builtin_amdgcn_sched_barrier(0);
-            c0 = n0;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -231,8 +250,7 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
             drh = MFMA16(WT[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, drh);
 #pragma unroll
             for (int i = 0; i < NXW; ++i) {
-                constexpr int dummy = 0; (void)dummy;
-                const int xt = W + 4 * i;
+                    const int xt = W + 4 * i;
                 dx[i] = MFMA16(WT[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
