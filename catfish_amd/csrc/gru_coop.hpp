@@ -211,7 +211,24 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
     constexpr int MX = CIN / 16;
     constexpr int NXW = MX > W ? (MX - W + 3) / 4 : 0;          // x-row tiles of this wave: W, W+4, ...
     constexpr int CF2 = 16 * (MI / 2) * 64;                     // candidate region in f32x2 units
-    const far_lds<f32x2> WT(reinterpret_cast<const f32x2*>(lds) + lane);      // candidate region | gate region
+    // A fragments as dwords through a register ring, like the forward kernel: one sequence p = 0..47 per step
+    // (16 k-steps of the candidate product, 32 of the gate product), 1 + NXW values each, fetched PF k-steps ahead.
+    constexpr int PF = CF_COOP_PF;
+    constexpr int NV = 1 + NXW;
+    static_assert(48 % PF == 0, "ring slots must line up across the step boundary");
+    const float* WF = lds + lane * 2;                           // f32x2 element e, component c at WF[e * 2 + c]
+    float ring[PF][NV];
+    auto fetch = [&](int p, float (&d)[NV]) {
+        p = p % 48;
+        const int e0 = p < 16 ? p * (MI / 2) * 64 : CF2 + (p - 16) * (MI / 2) * 64;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int tl = j == 0 ? MX + W : W + 4 * (j - 1);   // h-row tile first, then the x-row tiles
+            d[j] = WF[(e0 + (tl >> 1) * 64) * 2 + (tl & 1)];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(p, ring[p]);
     f32x4* XC = reinterpret_cast<f32x4*>(xch) + lane;           // da_c tiles [4][64]
     f32x4* XR = XC + 4 * 64;                                    // da_r
     f32x4* XU = XR + 4 * 64;                                    // da_u
@@ -243,16 +260,16 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
 #pragma unroll
         for (int i = 0; i < (NXW > 0 ? NXW : 1); ++i) dx[i] = (f32x4){0, 0, 0, 0};
         f32x4 drh = {0, 0, 0, 0}, dhg = {0, 0, 0, 0};
-        constexpr int HT = MX + W;                                // this wave's h-row tile
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const float b = dacf[ks >> 2][ks & 3];
-            drh = MFMA16(WT[(ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, drh);
+            float a[NV];
 #pragma unroll
-            for (int i = 0; i < NXW; ++i) {
-                    const int xt = W + 4 * i;
-                dx[i] = MFMA16(WT[(ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
-            }
+            for (int j = 0; j < NV; ++j) a[j] = ring[ks % PF][j];
+            fetch(ks + PF, ring[ks % PF]);
+            const float b = dacf[ks >> 2][ks & 3];
+            drh = MFMA16(a[0], b, drh);
+#pragma unroll
+            for (int i = 0; i < NXW; ++i) dx[i] = MFMA16(a[1 + i], b, dx[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         const f32x4 dar = drh * hp * r * (one - r);
@@ -264,13 +281,15 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
         for (int m = 0; m < 4; ++m) { dag[m] = XR[m * 64]; dag[4 + m] = XU[m * 64]; }
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) {
-            const float b = dag[ks >> 2][ks & 3];
-            dhg = MFMA16(WT[CF2 + (ks * (MI / 2) + (HT >> 1)) * 64][HT & 1], b, dhg);
+            const int p = 16 + ks;
+            float a[NV];
 #pragma unroll
-            for (int i = 0; i < NXW; ++i) {
-                const int xt = W + 4 * i;
-                dx[i] = MFMA16(WT[CF2 + (ks * (MI / 2) + (xt >> 1)) * 64][xt & 1], b, dx[i]);
-            }
+            for (int j = 0; j < NV; ++j) a[j] = ring[p % PF][j];
+            fetch(p + PF, ring[p % PF]);                            // wraps into the next step's candidate product
+            const float b = dag[ks >> 2][ks & 3];
+            dhg = MFMA16(a[0], b, dhg);
+#pragma unroll
+            for (int i = 0; i < NXW; ++i) dx[i] = MFMA16(a[1 + i], b, dx[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         dhc += dhg;
