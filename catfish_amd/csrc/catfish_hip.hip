@@ -790,6 +790,8 @@ struct cf_model {
     std::vector<Slot> slots;
     int fuse = 0;                             // all GRU layers in one launch (fp32 path, n_layers <= 3): 0 never, 1 always,
                                               // 2 auto = only for passes of >= 6 rounds, where the dynamic queues pay
+    float* d_xp = nullptr;                    // hoisted x projection of small calls: [xp_tiles][35][2][12][64] f32x4
+    int xp_tiles = 0;
     float* d_host_x = nullptr;                // cf_infer_host staging (grown on demand)
     float* d_host_p = nullptr;
     size_t host_stage_bytes = 0;
@@ -951,6 +953,7 @@ extern "C" void cf_model_destroy(cf_model* m) {
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (m->d_xp) (void)hipFree(m->d_xp);
     if (m->d_host_x) (void)hipFree(m->d_host_x);
     if (m->d_host_p) (void)hipFree(m->d_host_p);
     if (m->h_err) (void)hipHostFree(m->h_err);
@@ -1052,6 +1055,12 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
             if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
         }
         if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
+        if (e == hipSuccess && n_slots == 1 && m->np == 0) {
+            // small calls (up to n_cu / 4 tiles = 1024 windows): room for one layer's hoisted x projection
+            const int xpt = (int)std::min<int64_t>(m->cap_tiles, std::max(1, m->n_cu / 4));
+            e = hipMalloc((void**)&m->d_xp, (size_t)xpt * CF_T * 2 * 12 * 64 * sizeof(f32x4));
+            if (e == hipSuccess) m->xp_tiles = xpt;
+        }
         if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_err, sizeof(unsigned), hipHostMallocMapped);
         if (e == hipSuccess) { *m->h_err = 0u; e = hipHostGetDevicePointer((void**)&m->d_err, m->h_err, 0); }
         m->fuse = (m->np == 0 && hp->n_layers <= 3 && hp->fuse_layers >= 0) ? (hp->fuse_layers > 0 ? 1 : 2) : 0;
@@ -1139,8 +1148,14 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
         int rc = prof_begin(m, slot, s, &pi);
         if (rc != CF_OK) return rc;
         const int gx = std::min(n_tiles, std::max(1, m->n_cu / 2));
+        const f32x4* xp = nullptr;
+        if (CIN >= 32 && n_tiles <= m->xp_tiles) {        // few tiles: the x projection runs on the idle CUs first
+            xp = reinterpret_cast<const f32x4*>(m->d_xp);
+            hipLaunchKernelGGL((gru_xproj_kernel<CIN>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(X),
+                               reinterpret_cast<f32x4*>(m->d_xp), n_tiles);
+        }
         hipLaunchKernelGGL((gru_layer_coop_kernel<CIN, LAST>), dim3(gx, 2), dim3(256), (gru_pack_floats(CIN) + CF_COOP_XCH_FLOATS) * 4, s,
-                           wpack, reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles);
+                           wpack, reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles, xp);
         HIP_TRY(hipGetLastError());
         return prof_end(m, s, pi);
     }
@@ -1484,12 +1499,21 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
     if (n_tiles <= m->n_cu) {                // small batch: four waves per tile (latency mode), up to two rounds
         const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
-        if (cin == CF_C)
+        const bool hoist = n_tiles <= m->xp_tiles;
+        const f32x4* xp = hoist ? reinterpret_cast<const f32x4*>(m->d_xp) : nullptr;
+        if (cin == CF_C) {
+            if (hoist)
+                hipLaunchKernelGGL((gru_xproj_kernel<32>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
+                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles);
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
-                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
-        else
+                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp);
+        } else {
+            if (hoist)
+                hipLaunchKernelGGL((gru_xproj_kernel<128>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
+                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles);
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
-                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp);
+        }
         HIP_TRY(hipGetLastError());
         return CF_OK;
     }

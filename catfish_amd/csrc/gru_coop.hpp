@@ -14,16 +14,20 @@ __device__ __forceinline__ float pick4(const f32x4& a) { return a[W]; }
 #define CF_COOP_PF 4        // A-fragment prefetch depth (k-steps) of the cooperative forward kernel
 #endif
 
-template <int CIN, bool LAST, int W, bool STASH = false>
+// HOIST: the x projection (bias + Wx^T x_t, all 35 steps) was computed by gru_xproj_kernel into XP; the step then
+// starts from those accumulators -- the same fp32 values the in-kernel x part produces, so results are unchanged.
+template <int CIN, bool LAST, int W, bool STASH = false, bool HOIST = false>
 __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ X,
                                               f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
-                                              f32x4* __restrict__ S = nullptr) {
+                                              f32x4* __restrict__ S = nullptr, const f32x4* __restrict__ XP = nullptr) {
     constexpr int KGX = CIN / 16;
-    constexpr int KSX = CIN / 4;
+    constexpr int KSX = HOIST ? 0 : CIN / 4;          // k-steps of the x part done in this kernel
+    constexpr int XOFF = CIN / 4;                     // k-steps the packed x region holds
     constexpr int XN4 = gru_x_floats(CIN) / 4;
     constexpr int HG4 = gru_hg_floats() / 4;
     constexpr int BIAS = gru_bias_off(CIN);
     constexpr int DENSE = gru_dense_off(CIN);
+    (void)XOFF;
     const int q = lane >> 4;
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;
     const f32x4* WG = WX + XN4;
@@ -37,7 +41,14 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
     __syncthreads();
     f32x4 hown = {0, 0, 0, 0};
     f32x4 xc[KGX];
-    {
+    f32x4 xp[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};     // HOIST: r, u, c accumulators of the coming step
+    auto load_xp = [&](int t) {
+        const f32x4* src = XP + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
+        xp[0] = src[(0 + W) * 64]; xp[1] = src[(4 + W) * 64]; xp[2] = src[(8 + W) * 64];
+    };
+    if constexpr (HOIST) {
+        load_xp(dir ? (CF_T - 1) : 0);
+    } else {
         const int t0 = dir ? (CF_T - 1) : 0;
         const f32x4* src = X + ((int64_t)tile * CF_T + t0) * KGX * 64 + lane;
 #pragma unroll
@@ -65,7 +76,9 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
         f32x4 hf[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) hf[m] = hx[m * 64];
-        f32x4 ar = B4[(0 + W) * 4], au = B4[(4 + W) * 4], acnd = B4[(8 + W) * 4];
+        f32x4 ar, au, acnd;
+        if constexpr (HOIST) { ar = xp[0]; au = xp[1]; acnd = xp[2]; }
+        else { ar = B4[(0 + W) * 4]; au = B4[(4 + W) * 4]; acnd = B4[(8 + W) * 4]; }
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
             const float a0 = ring[ks % PF][0], a1 = ring[ks % PF][1], a2 = ring[ks % PF][2];
@@ -79,9 +92,13 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
         {
             int tn = dir ? (t - 1) : (t + 1);
             tn = tn < 0 ? 0 : (tn > CF_T - 1 ? CF_T - 1 : tn);
-            const f32x4* src = X + ((int64_t)tile * CF_T + tn) * KGX * 64 + lane;
+            if constexpr (HOIST) {
+                load_xp(tn);
+            } else {
+                const f32x4* src = X + ((int64_t)tile * CF_T + tn) * KGX * 64 + lane;
 #pragma unroll
-            for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+                for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -141,9 +158,49 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
     }
 }
 
+// The x projection of a whole layer for small calls: acc = bias + Wx^T x_t for every (tile, t, direction), no serial
+// dependency, so it spreads over the CUs the recurrence leaves idle (one workgroup per (tile, t), wave W = M-tiles
+// {r[W], u[W], c[W]}).  A fragments come straight from the packed weights in global memory (L2-resident, 24 KiB per
+// wave, all loads issued up front); k order and bias-first accumulation are those of the in-kernel x part.
+template <int CIN>
+__global__ __launch_bounds__(256) void gru_xproj_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
+                                                        f32x4* __restrict__ XP, int n_tiles) {
+    constexpr int KGX = CIN / 16;
+    constexpr int KSX = CIN / 4;
+    constexpr int PACK = gru_pack_floats(CIN);
+    constexpr int BIAS = gru_bias_off(CIN);
+    const int dir = blockIdx.y;
+    const int tile = blockIdx.x / CF_T, t = blockIdx.x - tile * CF_T;
+    const int lane = threadIdx.x & 63;
+    const int W = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* wp = wpack + (size_t)dir * PACK;
+    const float* wf = wp + lane * 4 + W;
+    float a[KSX][3];
+#pragma unroll
+    for (int ks = 0; ks < KSX; ++ks)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a[ks][g] = wf[((ks * 3 + g) * 64) * 4];
+    f32x4 xc[KGX];
+    const f32x4* src = X + ((int64_t)tile * CF_T + t) * KGX * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(wp + BIAS) + (lane >> 4);
+    f32x4 ar = B4[(0 + W) * 4], au = B4[(4 + W) * 4], ac = B4[(8 + W) * 4];
+#pragma unroll
+    for (int ks = 0; ks < KSX; ++ks) {
+        const float b = xc[ks >> 2][ks & 3];
+        ar = MFMA16(a[ks][0], b, ar);
+        au = MFMA16(a[ks][1], b, au);
+        ac = MFMA16(a[ks][2], b, ac);
+    }
+    f32x4* dst = XP + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
+    dst[(0 + W) * 64] = ar; dst[(4 + W) * 64] = au; dst[(8 + W) * 64] = ac;
+}
+
 template <int CIN, bool LAST>
 __global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
-                                                                f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles) {
+                                                                f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
+                                                                const f32x4* __restrict__ XP) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = gru_pack_floats(CIN);
     const int dir = blockIdx.y;
@@ -158,11 +215,20 @@ __global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __r
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* xch = lds + PACK;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        switch (wave) {
-            case 0: gru_tile_coop<CIN, LAST, 0>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
-            case 1: gru_tile_coop<CIN, LAST, 1>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
-            case 2: gru_tile_coop<CIN, LAST, 2>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
-            default: gru_tile_coop<CIN, LAST, 3>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+        if (XP) {
+            switch (wave) {
+                case 0: gru_tile_coop<CIN, LAST, 0, false, true>(lds, xch, lane, dir, tile, X, Y, P, n_tiles, nullptr, XP); break;
+                case 1: gru_tile_coop<CIN, LAST, 1, false, true>(lds, xch, lane, dir, tile, X, Y, P, n_tiles, nullptr, XP); break;
+                case 2: gru_tile_coop<CIN, LAST, 2, false, true>(lds, xch, lane, dir, tile, X, Y, P, n_tiles, nullptr, XP); break;
+                default: gru_tile_coop<CIN, LAST, 3, false, true>(lds, xch, lane, dir, tile, X, Y, P, n_tiles, nullptr, XP); break;
+            }
+        } else {
+            switch (wave) {
+                case 0: gru_tile_coop<CIN, LAST, 0>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+                case 1: gru_tile_coop<CIN, LAST, 1>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+                case 2: gru_tile_coop<CIN, LAST, 2>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+                default: gru_tile_coop<CIN, LAST, 3>(lds, xch, lane, dir, tile, X, Y, P, n_tiles); break;
+            }
         }
         __syncthreads();
     }
@@ -170,7 +236,8 @@ __global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __r
 
 template <int CIN>
 __global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
-                                                                    f32x4* __restrict__ Y, f32x4* __restrict__ S, int n_tiles) {
+                                                                    f32x4* __restrict__ Y, f32x4* __restrict__ S, int n_tiles,
+                                                                    const f32x4* __restrict__ XP) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = gru_pack_floats(CIN);
     const int dir = blockIdx.y;
@@ -185,11 +252,20 @@ __global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float*
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* xch = lds + PACK;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        switch (wave) {
-            case 0: gru_tile_coop<CIN, false, 0, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
-            case 1: gru_tile_coop<CIN, false, 1, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
-            case 2: gru_tile_coop<CIN, false, 2, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
-            default: gru_tile_coop<CIN, false, 3, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+        if (XP) {
+            switch (wave) {
+                case 0: gru_tile_coop<CIN, false, 0, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
+                case 1: gru_tile_coop<CIN, false, 1, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
+                case 2: gru_tile_coop<CIN, false, 2, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
+                default: gru_tile_coop<CIN, false, 3, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
+            }
+        } else {
+            switch (wave) {
+                case 0: gru_tile_coop<CIN, false, 0, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+                case 1: gru_tile_coop<CIN, false, 1, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+                case 2: gru_tile_coop<CIN, false, 2, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+                default: gru_tile_coop<CIN, false, 3, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+            }
         }
         __syncthreads();
     }
