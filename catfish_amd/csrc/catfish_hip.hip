@@ -1542,16 +1542,24 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
     if (n_tiles <= m->n_cu) {                // small batch: four waves per tile (latency mode), up to two rounds
         const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
-        if (cin == CF_C)
+        const int defer = n_tiles <= std::max(1, m->n_cu / 4) ? 1 : 0;      // few tiles: dx is formed afterwards on the idle CUs
+        if (cin == CF_C) {
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
-                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
-        else
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer);
+            if (defer)
+                hipLaunchKernelGGL((gru_dx_kernel<32>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
+                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles);
+        } else {
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
-                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer);
+            if (defer)
+                hipLaunchKernelGGL((gru_dx_kernel<128>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
+                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles);
+        }
         HIP_TRY(hipGetLastError());
         return CF_OK;
     }

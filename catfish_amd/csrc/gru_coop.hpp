@@ -278,14 +278,16 @@ __global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float*
 // exchanged through 12 KiB of LDS (three barriers per step).  Same arithmetic per element as
 // gru_train_bwd_kernel.
 // ------------------------------------------------------------------------------------------
-template <int CIN, int W>
+// DEFER: the input gradient dx (the x-row tiles of both products) is off the serial chain; it is left to
+// gru_dx_kernel, which forms it from the stored pre-activation gradients on the CUs the recurrence leaves idle.
+template <int CIN, int W, bool DEFER = false>
 __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ Y,
                                                   const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
                                                   const f32x4* __restrict__ DY2, const f32x4* __restrict__ DSC, f32x4* __restrict__ DX,
                                                   f32x4* __restrict__ DA, int n_tiles) {
     constexpr int MI = (CIN + CF_H) / 16;
     constexpr int MX = CIN / 16;
-    constexpr int NXW = MX > W ? (MX - W + 3) / 4 : 0;          // x-row tiles of this wave: W, W+4, ...
+    constexpr int NXW = DEFER ? 0 : (MX > W ? (MX - W + 3) / 4 : 0);     // x-row tiles of this wave: W, W+4, ...
     constexpr int CF2 = 16 * (MI / 2) * 64;                     // candidate region in f32x2 units
     // A fragments as dwords through a register ring, like the forward kernel: one sequence p = 0..47 per step
     // (16 k-steps of the candidate product, 32 of the gate product), 1 + NXW values each, fetched PF k-steps ahead.
@@ -382,7 +384,8 @@ template <int CIN>
 __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ Y,
                                                                     const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
                                                                     const f32x4* __restrict__ DY2, const f32x4* __restrict__ DSC,
-                                                                    f32x4* __restrict__ DX, f32x4* __restrict__ DA, int n_tiles) {
+                                                                    f32x4* __restrict__ DX, f32x4* __restrict__ DA, int n_tiles,
+                                                                    int defer_dx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = ((CIN + CF_H) / 16 / 2) * 128 * 48;      // = gtb_pack_floats(CIN)
     const int dir = blockIdx.y;
@@ -397,11 +400,61 @@ __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float*
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* xch = lds + PACK;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        switch (wave) {
-            case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-            case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-            case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-            default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+        if (defer_dx) {
+            switch (wave) {
+                case 0: gru_bwd_tile_coop<CIN, 0, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                case 1: gru_bwd_tile_coop<CIN, 1, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                case 2: gru_bwd_tile_coop<CIN, 2, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                default: gru_bwd_tile_coop<CIN, 3, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+            }
+        } else {
+            switch (wave) {
+                case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+            }
         }
+    }
+}
+
+// dx of one layer for small batches, from the stored pre-activation gradients: one workgroup per (tile, t), wave W =
+// x-row tiles W, W+4, ...; A fragments straight from the packed backward weights in global memory.  Same k order as
+// the in-kernel version (16 k-steps against da_c, then 32 against da_r | da_u).
+template <int CIN>
+__global__ __launch_bounds__(256) void gru_dx_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ DA,
+                                                     f32x4* __restrict__ DX, int n_tiles) {
+    constexpr int MI = (CIN + CF_H) / 16;
+    constexpr int MX = CIN / 16;
+    constexpr int PACK = (MI / 2) * 128 * 48;
+    constexpr int CF2 = 16 * (MI / 2) * 64;
+    constexpr int NX = (MX + 3) / 4;                              // x-row tiles per wave (waves beyond MX idle)
+    const int dir = blockIdx.y;
+    const int tile = blockIdx.x / CF_T, t = blockIdx.x - tile * CF_T;
+    const int lane = threadIdx.x & 63;
+    const int W = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (W >= MX) return;
+    const float* wf = wpack + (size_t)dir * PACK + lane * 2;
+    const int64_t base = (int64_t)tile * CF_T + t;
+    const f32x4* dap = DA + (base * 2 + dir) * 12 * 64 + lane;
+    f32x4 dag[8], dac[4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) dag[m] = dap[m * 64];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dac[m] = dap[(8 + m) * 64];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int xt = W + 4 * i;
+        if (xt >= MX) break;
+        const float* wt = wf + ((xt >> 1) * 64) * 2 + (xt & 1);
+        float a[48];
+#pragma unroll
+        for (int p = 0; p < 48; ++p) a[p] = wt[(size_t)(p < 16 ? p * (MI / 2) * 64 : CF2 + (p - 16) * (MI / 2) * 64) * 2];
+        f32x4 dx = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) dx = MFMA16(a[ks], dac[ks >> 2][ks & 3], dx);
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) dx = MFMA16(a[16 + ks], dag[ks >> 2][ks & 3], dx);
+        DX[(((int64_t)dir * n_tiles * CF_T + base) * MX + xt) * 64 + lane] = dx;
     }
 }
