@@ -72,6 +72,23 @@ def test_ragged_window_counts_random_weights(n_windows):
     assert err < TOL, err
 
 
+@pytest.mark.parametrize("n_windows", [1024, 1040, 4096, 4112])
+def test_launch_regime_boundaries(n_windows):
+    """One pass each side of the two regime switches of the fp32 path: hoisted x projection up to CUs/4 tiles
+    (1024 windows), latency-mode kernels up to CUs tiles (4096 windows), one wave per tile beyond."""
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=5)
+    rng = np.random.default_rng(n_windows)
+    x = rng.normal(0, 1.5, size=(n_windows, 35)).astype(np.float32)
+    eng = HipEngine(w, device=0, max_windows_per_pass=8192)
+    try:
+        got = eng.infer_host(x)
+    finally:
+        eng.close()
+    want = oracle.forward(x, w, np.float32)
+    assert np.abs(got - want).max() < 2e-5
+
+
 def test_device_path_matches_host_path(engine, golden_read):
     torch = pytest.importorskip("torch")
     x = torch.from_numpy(golden_read["x"]).cuda()
