@@ -1056,8 +1056,10 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         }
         if (e == hipSuccess && n_slots > 1) e = hipEventCreateWithFlags(&m->fork, hipEventDisableTiming);
         if (e == hipSuccess && n_slots == 1 && m->np == 0) {
-            // small calls (up to n_cu / 4 tiles = 1024 windows): room for one layer's hoisted x projection
-            const int xpt = (int)std::min<int64_t>(m->cap_tiles, std::max(1, m->n_cu / 4));
+            // small calls: room for one layer's hoisted x projection (CATFISH_HOIST_TILES: A/B knob for tools/)
+            // measured crossover (tools/bench_latency.py with CATFISH_HOIST_TILES): hoisting pays up to ~48 tiles = 768 windows
+            int xpt = (int)std::min<int64_t>(m->cap_tiles, std::max(1, 3 * m->n_cu / 16));
+            if (getenv("CATFISH_HOIST_TILES")) xpt = std::max(1, std::min(atoi(getenv("CATFISH_HOIST_TILES")), (int)m->cap_tiles));
             e = hipMalloc((void**)&m->d_xp, (size_t)xpt * CF_T * 2 * 12 * 64 * sizeof(f32x4));
             if (e == hipSuccess) m->xp_tiles = xpt;
         }
@@ -1151,8 +1153,8 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
         const f32x4* xp = nullptr;
         if (CIN >= 32 && n_tiles <= m->xp_tiles) {        // few tiles: the x projection runs on the idle CUs first
             xp = reinterpret_cast<const f32x4*>(m->d_xp);
-            hipLaunchKernelGGL((gru_xproj_kernel<CIN>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(X),
-                               reinterpret_cast<f32x4*>(m->d_xp), n_tiles);
+            hipLaunchKernelGGL((gru_xproj_kernel<CIN>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(X),
+                               reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
         }
         hipLaunchKernelGGL((gru_layer_coop_kernel<CIN, LAST>), dim3(gx, 2), dim3(256), (gru_pack_floats(CIN) + CF_COOP_XCH_FLOATS) * 4, s,
                            wpack, reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles, xp);
@@ -1503,14 +1505,14 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
         const f32x4* xp = hoist ? reinterpret_cast<const f32x4*>(m->d_xp) : nullptr;
         if (cin == CF_C) {
             if (hoist)
-                hipLaunchKernelGGL((gru_xproj_kernel<32>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
-                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles);
+                hipLaunchKernelGGL((gru_xproj_kernel<32>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
+                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
                                reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp);
         } else {
             if (hoist)
-                hipLaunchKernelGGL((gru_xproj_kernel<128>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
-                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles);
+                hipLaunchKernelGGL((gru_xproj_kernel<128>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
+                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
                                reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp);
         }
@@ -1542,23 +1544,23 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
     if (n_tiles <= m->n_cu) {                // small batch: four waves per tile (latency mode), up to two rounds
         const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
-        const int defer = n_tiles <= std::max(1, m->n_cu / 4) ? 1 : 0;      // few tiles: dx is formed afterwards on the idle CUs
+        const int defer = n_tiles <= m->xp_tiles ? 1 : 0;                    // few tiles: dx is formed afterwards on the idle CUs
         if (cin == CF_C) {
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
                                reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer);
             if (defer)
-                hipLaunchKernelGGL((gru_dx_kernel<32>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
-                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles);
+                hipLaunchKernelGGL((gru_dx_kernel<32>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
+                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles, cf_xproj_chunks(n_tiles));
         } else {
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
                                reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer);
             if (defer)
-                hipLaunchKernelGGL((gru_dx_kernel<128>), dim3(n_tiles * CF_T, 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
-                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles);
+                hipLaunchKernelGGL((gru_dx_kernel<128>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
+                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles, cf_xproj_chunks(n_tiles));
         }
         HIP_TRY(hipGetLastError());
         return CF_OK;

@@ -10,6 +10,9 @@
 
 template <int W>
 __device__ __forceinline__ float pick4(const f32x4& a) { return a[W]; }
+// workgroups per tile in gru_xproj_kernel / gru_dx_kernel: one step each while the call is tiny (parallelism), five steps
+// each otherwise (the weight fragments are fetched from L2 once per workgroup)
+static inline int cf_xproj_chunks(int n_tiles) { return n_tiles <= 8 ? CF_T : 7; }
 #ifndef CF_COOP_PF
 #define CF_COOP_PF 4        // A-fragment prefetch depth (k-steps) of the cooperative forward kernel
 #endif
@@ -159,42 +162,46 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
 }
 
 // The x projection of a whole layer for small calls: acc = bias + Wx^T x_t for every (tile, t, direction), no serial
-// dependency, so it spreads over the CUs the recurrence leaves idle (one workgroup per (tile, t), wave W = M-tiles
-// {r[W], u[W], c[W]}).  A fragments come straight from the packed weights in global memory (L2-resident, 24 KiB per
+// dependency, so it spreads over the CUs the recurrence leaves idle (one workgroup per tile and chunk of steps,
+// wave W = M-tiles {r[W], u[W], c[W]}).  A fragments come straight from the packed weights in global memory (L2-resident, 24 KiB per
 // wave, all loads issued up front); k order and bias-first accumulation are those of the in-kernel x part.
 template <int CIN>
 __global__ __launch_bounds__(256) void gru_xproj_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
-                                                        f32x4* __restrict__ XP, int n_tiles) {
+                                                        f32x4* __restrict__ XP, int n_tiles, int chunks) {
     constexpr int KGX = CIN / 16;
     constexpr int KSX = CIN / 4;
     constexpr int PACK = gru_pack_floats(CIN);
     constexpr int BIAS = gru_bias_off(CIN);
     const int dir = blockIdx.y;
-    const int tile = blockIdx.x / CF_T, t = blockIdx.x - tile * CF_T;
+    const int tile = blockIdx.x / chunks, chunk = blockIdx.x - tile * chunks;
     const int lane = threadIdx.x & 63;
     const int W = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* wp = wpack + (size_t)dir * PACK;
     const float* wf = wp + lane * 4 + W;
-    float a[KSX][3];
+    float a[KSX][3];                                   // this wave's fragments stay in registers for the whole chunk of steps
 #pragma unroll
     for (int ks = 0; ks < KSX; ++ks)
 #pragma unroll
         for (int g = 0; g < 3; ++g) a[ks][g] = wf[((ks * 3 + g) * 64) * 4];
-    f32x4 xc[KGX];
-    const f32x4* src = X + ((int64_t)tile * CF_T + t) * KGX * 64 + lane;
-#pragma unroll
-    for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
     const f32x4* B4 = reinterpret_cast<const f32x4*>(wp + BIAS) + (lane >> 4);
-    f32x4 ar = B4[(0 + W) * 4], au = B4[(4 + W) * 4], ac = B4[(8 + W) * 4];
+    const f32x4 br = B4[(0 + W) * 4], bu = B4[(4 + W) * 4], bc = B4[(8 + W) * 4];
+    const int TL = (CF_T + chunks - 1) / chunks;
+    for (int t = chunk * TL; t < min((chunk + 1) * TL, CF_T); ++t) {
+        f32x4 xc[KGX];
+        const f32x4* src = X + ((int64_t)tile * CF_T + t) * KGX * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < KSX; ++ks) {
-        const float b = xc[ks >> 2][ks & 3];
-        ar = MFMA16(a[ks][0], b, ar);
-        au = MFMA16(a[ks][1], b, au);
-        ac = MFMA16(a[ks][2], b, ac);
+        for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+        f32x4 ar = br, au = bu, ac = bc;
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+            const float b = xc[ks >> 2][ks & 3];
+            ar = MFMA16(a[ks][0], b, ar);
+            au = MFMA16(a[ks][1], b, au);
+            ac = MFMA16(a[ks][2], b, ac);
+        }
+        f32x4* dst = XP + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
+        dst[(0 + W) * 64] = ar; dst[(4 + W) * 64] = au; dst[(8 + W) * 64] = ac;
     }
-    f32x4* dst = XP + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
-    dst[(0 + W) * 64] = ar; dst[(4 + W) * 64] = au; dst[(8 + W) * 64] = ac;
 }
 
 template <int CIN, bool LAST>
@@ -423,38 +430,41 @@ __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float*
 // the in-kernel version (16 k-steps against da_c, then 32 against da_r | da_u).
 template <int CIN>
 __global__ __launch_bounds__(256) void gru_dx_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ DA,
-                                                     f32x4* __restrict__ DX, int n_tiles) {
+                                                     f32x4* __restrict__ DX, int n_tiles, int chunks) {
     constexpr int MI = (CIN + CF_H) / 16;
     constexpr int MX = CIN / 16;
     constexpr int PACK = (MI / 2) * 128 * 48;
     constexpr int CF2 = 16 * (MI / 2) * 64;
     constexpr int NX = (MX + 3) / 4;                              // x-row tiles per wave (waves beyond MX idle)
     const int dir = blockIdx.y;
-    const int tile = blockIdx.x / CF_T, t = blockIdx.x - tile * CF_T;
+    const int tile = blockIdx.x / chunks, chunk = blockIdx.x - tile * chunks;
     const int lane = threadIdx.x & 63;
     const int W = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (W >= MX) return;
     const float* wf = wpack + (size_t)dir * PACK + lane * 2;
-    const int64_t base = (int64_t)tile * CF_T + t;
-    const f32x4* dap = DA + (base * 2 + dir) * 12 * 64 + lane;
-    f32x4 dag[8], dac[4];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) dag[m] = dap[m * 64];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) dac[m] = dap[(8 + m) * 64];
+    const int TL = (CF_T + chunks - 1) / chunks;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int xt = W + 4 * i;
         if (xt >= MX) break;
         const float* wt = wf + ((xt >> 1) * 64) * 2 + (xt & 1);
-        float a[48];
+        float a[48];                                   // one x-row tile's fragments, kept for the whole chunk of steps
 #pragma unroll
         for (int p = 0; p < 48; ++p) a[p] = wt[(size_t)(p < 16 ? p * (MI / 2) * 64 : CF2 + (p - 16) * (MI / 2) * 64) * 2];
-        f32x4 dx = {0, 0, 0, 0};
+        for (int t = chunk * TL; t < min((chunk + 1) * TL, CF_T); ++t) {
+            const int64_t base = (int64_t)tile * CF_T + t;
+            const f32x4* dap = DA + (base * 2 + dir) * 12 * 64 + lane;
+            f32x4 dag[8], dac[4];
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) dx = MFMA16(a[ks], dac[ks >> 2][ks & 3], dx);
+            for (int m = 0; m < 8; ++m) dag[m] = dap[m * 64];
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) dx = MFMA16(a[16 + ks], dag[ks >> 2][ks & 3], dx);
-        DX[(((int64_t)dir * n_tiles * CF_T + base) * MX + xt) * 64 + lane] = dx;
+            for (int m = 0; m < 4; ++m) dac[m] = dap[(8 + m) * 64];
+            f32x4 dx = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) dx = MFMA16(a[ks], dac[ks >> 2][ks & 3], dx);
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) dx = MFMA16(a[16 + ks], dag[ks >> 2][ks & 3], dx);
+            DX[(((int64_t)dir * n_tiles * CF_T + base) * MX + xt) * 64 + lane] = dx;
+        }
     }
 }

@@ -10,7 +10,7 @@ w = bench.load_weights()
 out = {}
 for prec in ("fp32", "bf16x3", "bf16"):
     eng = HipEngine(w, device=0, max_windows_per_pass=4096, precision=prec)
-    for n in (118, 256, 2048, 4096):
+    for n in (118, 256, 512, 768, 1024, 2048, 4096):
         x = torch.randn(n, 35, device="cuda")
         y = torch.empty(n * 35, device="cuda")
         for _ in range(5):
