@@ -67,6 +67,10 @@ SYMBOLS = {
     "cf_model_destroy": (None, [C.c_void_p]),
     "cf_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cf_infer_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cf_infer_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cf_infer_host_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cf_check_error": (C.c_int, [C.c_void_p]),
+    "cf_launch_regimes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "cf_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "cf_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -3,7 +3,9 @@
 Same options (``-i/--input-dir``, ``-s/--split-dir``, ``-c/--chunk-size`` default 1000) and the
 same pipeline: load the bundled ResNetRNN, predict homopolymer stretches per read, merge them
 into chunks of at least ``chunk_size`` samples, derive the non-HP complement, split the reads.
-All reads of the directory go through packed multi-read launches instead of one call per file.
+All reads of the directory go through packed multi-read launches instead of one call per file, and
+the per-file loop (catfish/catfish:50-56) shards over the GPUs of the node: ``--gpus N`` (an MI355X
+addition) or ``python -m torch.distributed.run --nproc-per-node N -m catfish_amd.cli ...``.
 
 The FAST5 splitter (catfish/split_f5.py) is disk I/O around h5py and out of scope: when h5py
 is not installed the chunk coordinates are written as JSON next to the would-be split files.
@@ -14,7 +16,6 @@ import datetime
 import json
 import os
 
-from . import batching
 from . import infer
 from . import neural_network
 
@@ -63,51 +64,94 @@ def nonhp_complement(merged_positions, len_read):
     return out
 
 
+def chunks_of_read(hp_positions, len_read, chunk_size=1000):
+    """catfish/catfish:57-82 for one read: (merged HP chunks or None, non-HP stretches)."""
+    if hp_positions != []:
+        merged_positions = merge_positions(hp_positions, len_read, chunk_size)
+        return merged_positions, nonhp_complement(merged_positions, len_read)
+    return None, [([(0, len_read), len_read])]                 # catfish:82 (kept verbatim)
+
+
 def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN", network_type="ResNetRNN",
-                 checkpoint=30000, device=0):
-    """Body of the reference's ``main`` (catfish/catfish:23-94) up to the split step."""
-    hp_dict = {}
-    nonhp_dict = {}
-    temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
-    temp_dir_hp = "{}/HP".format(os.path.abspath(temp_dir))
-    temp_dir_nonhp = "{}/nonHP".format(os.path.abspath(temp_dir))
-    os.makedirs(temp_dir_hp)          # raises if they exist, like the reference (:37-38)
-    os.mkdir(temp_dir_nonhp)
+                 checkpoint=30000, device=None, precision="fp32"):
+    """Body of the reference's ``main`` (catfish/catfish:23-94) up to the split step.
 
-    input_dir = os.path.abspath(input_dir)
-    input_files = os.listdir(input_dir)
+    Under ``torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the per-file loop of
+    catfish/catfish:50-56 is sharded: every rank loads and classifies its own files on its own MI355X
+    (``sharding.infer_files_sharded``) and rank 0, which gathers the spans over a gloo group, does the merging and
+    writes the output.  Returns ``(hp_dict, nonhp_dict)`` on rank 0 and ``(None, None)`` on the other ranks.
+    """
+    from . import sharding
+    rank, world, local_rank = sharding.dist_env()
+    own_group = sharding.init_host_group()
+    try:
+        hp_dict = {}
+        nonhp_dict = {}
+        temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
+        temp_dir_hp = "{}/HP".format(os.path.abspath(temp_dir))
+        temp_dir_nonhp = "{}/nonHP".format(os.path.abspath(temp_dir))
+        if rank == 0:
+            os.makedirs(temp_dir_hp)          # raises if they exist, like the reference (:37-38)
+            os.mkdir(temp_dir_nonhp)
 
-    t1 = datetime.datetime.now()
-    network_path = os.path.abspath(network_path)
-    # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
-    # tail instead of 8 % and the three layers go out as one dynamically scheduled launch (DESIGN.md, section 4).
-    max_windows = 131072 if len(input_files) > 400 else 32768
-    model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint, device=device,
-                                        max_windows_per_pass=max_windows)
-    print("Loaded model in {}".format(datetime.datetime.now() - t1))
+        input_dir = os.path.abspath(input_dir)
+        input_files = sorted(os.listdir(input_dir)) if world > 1 else os.listdir(input_dir)   # one order on every rank
 
-    print("Checking for homopolymers in raw signal..")
-    t2 = datetime.datetime.now()
-    signals = [infer.load_raw("{}/{}".format(input_dir, f)) for f in input_files]
-    results = batching.infer_reads(model, signals, max_windows=max_windows)
-    for fast5_file, (hp_positions, len_read) in zip(input_files, results):
-        if hp_positions != []:
-            merged_positions = merge_positions(hp_positions, len_read, chunk_size)
-            hp_dict[fast5_file] = merged_positions
-            nonhp_dict[fast5_file] = nonhp_complement(merged_positions, len_read)
-        else:
-            nonhp_dict[fast5_file] = [([(0, len_read), len_read])]     # catfish:82 (kept verbatim)
-    print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
+        t1 = datetime.datetime.now()
+        network_path = os.path.abspath(network_path)
+        # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
+        # tail instead of 8 % and the three layers go out as one dynamically scheduled launch (DESIGN.md, section 4).
+        max_windows = 131072 if len(input_files) > 400 * world else 32768
+        model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint,
+                                            device=_pick_device(local_rank) if device is None else device,
+                                            max_windows_per_pass=max_windows, precision=precision)
+        if rank == 0:
+            print("Loaded model in {}".format(datetime.datetime.now() - t1))
+            print("Checking for homopolymers in raw signal..")
+        t2 = datetime.datetime.now()
+        results = sharding.infer_files_sharded(model, ["{}/{}".format(input_dir, f) for f in input_files],
+                                               max_samples_per_batch=max_windows * infer.WINDOW_SIZE,
+                                               gather_group=sharding.host_gather_group())
+        if rank != 0:
+            return None, None
+        for fast5_file, (hp_positions, len_read) in zip(input_files, results):
+            merged_positions, nonhp = chunks_of_read(hp_positions, len_read, chunk_size)
+            if merged_positions is not None:
+                hp_dict[fast5_file] = merged_positions
+            nonhp_dict[fast5_file] = nonhp
+        print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
 
-    print("Splitting reads...")
-    t3 = datetime.datetime.now()
-    with open(os.path.join(temp_dir, "hp_positions.json"), "w") as fh:
-        json.dump(hp_dict, fh)
-    with open(os.path.join(temp_dir, "nonhp_positions.json"), "w") as fh:
-        json.dump(nonhp_dict, fh)
-    print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
-        temp_dir, datetime.datetime.now() - t3))
-    return hp_dict, nonhp_dict
+        print("Splitting reads...")
+        t3 = datetime.datetime.now()
+        with open(os.path.join(temp_dir, "hp_positions.json"), "w") as fh:
+            json.dump(hp_dict, fh)
+        with open(os.path.join(temp_dir, "nonhp_positions.json"), "w") as fh:
+            json.dump(nonhp_dict, fh)
+        print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
+            temp_dir, datetime.datetime.now() - t3))
+        return hp_dict, nonhp_dict
+    finally:
+        if own_group:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _pick_device(local_rank):
+    """One process per GPU: rank r of the node drives device r.  ``CATFISH_DEVICE`` pins every rank to one device
+    instead (rehearsing the multi-rank path on a box with fewer GPUs than ranks)."""
+    return int(os.environ["CATFISH_DEVICE"]) if "CATFISH_DEVICE" in os.environ else local_rank
+
+
+def launch_ranks(n_gpus, argv):
+    """Start ``n_gpus`` ranks of this CLI under torch.distributed.run as a CHILD process (never an exec: nothing in
+    this process may have touched the GPU, and the child's exit code becomes ours)."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+           "-m", "catfish_amd.cli"] + list(argv)
+    return subprocess.call(cmd)
 
 
 def _build_click_main():
@@ -118,12 +162,22 @@ def _build_click_main():
     @click.option("--split-dir", "-s", help="Path to directory to save split reads to")
     @click.option("--chunk-size", "-c", help="Chunk size for homopolymer containing stretches", default=1000,
                   show_default=True)
-    def main(input_dir, split_dir, chunk_size):
+    @click.option("--gpus", "-g", default=1, show_default=True,
+                  help="MI355X devices of this node to shard the reads over (one process per GPU)")
+    @click.option("--network-path", default="ResNetRNN", show_default=True, help="Directory of the trained network")
+    @click.option("--precision", default="fp32", show_default=True, type=click.Choice(["fp32", "bf16x3", "bf16"]),
+                  help="Arithmetic of the biGRU matmuls")
+    def main(input_dir, split_dir, chunk_size, gpus, network_path, precision):
         """
         A tool with a neural network as basis to predict the presence of
         homopolymers in the raw signal from a MinION sequencer.
         """
-        run_pipeline(input_dir, split_dir, chunk_size)
+        if gpus > 1 and "WORLD_SIZE" not in os.environ:
+            import sys
+            argv = ["-i", input_dir, "-s", split_dir, "-c", str(chunk_size), "--network-path", network_path,
+                    "--precision", precision]
+            sys.exit(launch_ranks(gpus, argv))
+        run_pipeline(input_dir, split_dir, chunk_size, network_path=network_path, precision=precision)
 
     return main
 

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x_
 // transposing the [tile][t][16] partials back to the reference's window-major order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, float bias, float* __restrict__ probs,
-                                                   int64_t n_windows, int n_tiles, int tile_shift) {
+                                                   float* __restrict__ logits, int64_t n_windows, int n_tiles, int tile_shift) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_windows * CF_T) return;
     const int64_t w = idx / CF_T;
@@ -577,7 +577,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, 
     const int tw = 1 << tile_shift;
     const int wl = (int)(w & (tw - 1));
     const float z = P[((tile)*CF_T + t) * tw + wl] + P[(((int64_t)n_tiles + tile) * CF_T + t) * tw + wl] + bias;
-    probs[idx] = 1.0f / (1.0f + expf(-z));
+    if (logits) logits[idx] = z;
+    if (probs) probs[idx] = 1.0f / (1.0f + expf(-z));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -955,7 +956,6 @@ extern "C" void cf_model_destroy(cf_model* m) {
     }
     if (m->d_xp) (void)hipFree(m->d_xp);
     if (m->d_host_x) (void)hipFree(m->d_host_x);
-    if (m->d_host_p) (void)hipFree(m->d_host_p);
     if (m->h_err) (void)hipHostFree(m->h_err);
     if (m->fork) (void)hipEventDestroy(m->fork);
     for (auto& e : m->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1205,7 +1205,10 @@ static int launch_gru_bf16_layer(cf_model* m, int l, bool last, const float* cur
                 : launch_gru_bf16<128, false, NP>(m, wp, cur, y, p, n_tiles32, s, SLOT_GRU);
 }
 
-static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_windows, float* probs, hipStream_t s) {
+// fuse_layers = auto: the dynamically scheduled single launch pays from ~6 full-chip rounds of 8-tile groups per pass
+static int cf_fuse_min_groups(int n_cu) { return 6 * std::max(1, n_cu / 2); }
+
+static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_windows, float* probs, float* logits, hipStream_t s) {
     const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
     const int n_tiles32 = (int)((n_windows + 2 * CF_TILE - 1) / (2 * CF_TILE));
     int rc;
@@ -1264,7 +1267,7 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     }
     const float* cur = m->hp.n_layers_res == 0 ? sl.d_a[0] : sl.d_a[(m->hp.n_layers_res - 1) & 1];
     // GRU layers
-    const bool fuse_now = m->fuse == 1 || (m->fuse == 2 && (n_tiles + 7) / 8 >= 6 * std::max(1, m->n_cu / 2));
+    const bool fuse_now = m->fuse == 1 || (m->fuse == 2 && (n_tiles + 7) / 8 >= cf_fuse_min_groups(m->n_cu));
     if (fuse_now) {
         cf_fused_args a;
         for (int l = 0; l < 3; ++l) a.w[l] = l < m->hp.n_layers ? m->d_gru[l] : nullptr;
@@ -1309,7 +1312,7 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     // head
     if ((rc = prof_begin(m, SLOT_HEAD, s, &pi)) != CF_OK) return rc;
     const int64_t total = n_windows * CF_T;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sl.d_p, m->dense_bias, probs, n_windows,
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sl.d_p, m->dense_bias, probs, logits, n_windows,
                        m->np > 0 ? n_tiles32 : n_tiles, m->np > 0 ? 5 : 4);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
@@ -1317,14 +1320,30 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     return CF_OK;
 }
 
-extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* probs, void* stream) {
+static const char* k_fused_timeout_msg = "a fused biGRU launch timed out waiting for a producer workgroup; its results are invalid "
+                                         "(create the model with fuse_layers = -1)";
+
+extern "C" int cf_check_error(cf_model* m) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_check_error: null model");
+    if (m->h_err && *m->h_err) return fail(CF_ERR_HIP, k_fused_timeout_msg);
+    return CF_OK;
+}
+
+extern "C" int cf_launch_regimes(const cf_model* m, int64_t out[4]) {
+    if (!m || !out) return fail(CF_ERR_INVALID, "cf_launch_regimes: null argument");
+    out[0] = m->n_cu;
+    out[1] = (int64_t)m->xp_tiles * CF_TILE;
+    out[2] = m->np == 0 ? (int64_t)m->n_cu * CF_TILE : 0;
+    out[3] = m->fuse == 1 ? 1 : (m->fuse == 2 ? ((int64_t)8 * cf_fuse_min_groups(m->n_cu) - 8) * CF_TILE + 1 : 0);
+    return CF_OK;
+}
+
+extern "C" int cf_infer_logits(cf_model* m, const float* x, int64_t n_windows, float* probs, float* logits, void* stream) {
     if (!m) return fail(CF_ERR_INVALID, "cf_infer: null model");
     if (n_windows < 0) return fail(CF_ERR_INVALID, "cf_infer: negative n_windows");
     if (n_windows == 0) return CF_OK;
-    if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer: null buffer");
-    if (m->h_err && *m->h_err)
-        return fail(CF_ERR_HIP, "an earlier fused GRU launch timed out waiting for a producer workgroup; its results are invalid "
-                                "(create the model with fuse_layers = -1)");
+    if (!x || (!probs && !logits)) return fail(CF_ERR_INVALID, "cf_infer: null buffer");
+    if (m->h_err && *m->h_err) return fail(CF_ERR_HIP, k_fused_timeout_msg);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     m->prof = m->prof_every > 0 && (m->prof_calls++ % m->prof_every) == 0;
@@ -1339,7 +1358,8 @@ extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* p
         // small calls (a single read) are launch-bound: no fork/join
         for (int64_t off = 0; off < n_windows; off += m->cap_windows) {
             const int64_t n = std::min(m->cap_windows, n_windows - off);
-            const int rc = run_pass(m, m->slots[0], x + off * CF_T, n, probs + off * CF_T, s);
+            const int rc = run_pass(m, m->slots[0], x + off * CF_T, n, probs ? probs + off * CF_T : nullptr,
+                                    logits ? logits + off * CF_T : nullptr, s);
             if (rc != CF_OK) return rc;
         }
         if (n_slots > 1) {
@@ -1356,7 +1376,7 @@ extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* p
     for (int64_t off = 0; off < n_windows; off += chunk, ++k) {
         const int64_t n = std::min(chunk, n_windows - off);
         cf_model::Slot& sl = m->slots[k % n_slots];
-        const int rc = run_pass(m, sl, x + off * CF_T, n, probs + off * CF_T, sl.stream);
+        const int rc = run_pass(m, sl, x + off * CF_T, n, probs ? probs + off * CF_T : nullptr, logits ? logits + off * CF_T : nullptr, sl.stream);
         if (rc != CF_OK) return rc;
     }
     for (auto& sl : m->slots) {
@@ -1366,34 +1386,44 @@ extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* p
     return CF_OK;
 }
 
-extern "C" int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, float* probs) {
+extern "C" int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* probs, void* stream) {
+    if (n_windows > 0 && !probs) return fail(CF_ERR_INVALID, "cf_infer: null buffer");
+    return cf_infer_logits(m, x, n_windows, probs, nullptr, stream);
+}
+
+extern "C" int cf_infer_host_logits(cf_model* m, const float* x, int64_t n_windows, float* probs, float* logits) {
     if (!m) return fail(CF_ERR_INVALID, "cf_infer_host: null model");
     if (n_windows < 0) return fail(CF_ERR_INVALID, "cf_infer_host: negative n_windows");
     if (n_windows == 0) return CF_OK;
-    if (!x || !probs) return fail(CF_ERR_INVALID, "cf_infer_host: null buffer");
+    if (!x || (!probs && !logits)) return fail(CF_ERR_INVALID, "cf_infer_host: null buffer");
     HIP_TRY(hipSetDevice(m->device));
     const size_t bytes = (size_t)n_windows * CF_T * sizeof(float);
-    // device staging buffers are kept across calls (the reference calls infer once per read)
+    // device staging buffers are kept across calls (the reference calls infer once per read): x, probs, logits
     if (m->host_stage_bytes < bytes) {
         if (m->d_host_x) (void)hipFree(m->d_host_x);
-        if (m->d_host_p) (void)hipFree(m->d_host_p);
         m->d_host_x = m->d_host_p = nullptr;
         m->host_stage_bytes = 0;
-        const size_t cap = bytes + bytes / 4;
-        HIP_TRY(hipMalloc((void**)&m->d_host_x, cap));
-        hipError_t e2 = hipMalloc((void**)&m->d_host_p, cap);
-        if (e2 != hipSuccess) { (void)hipFree(m->d_host_x); m->d_host_x = nullptr; return fail(CF_ERR_NOMEM, "cf_infer_host: hipMalloc failed"); }
+        const size_t cap = (bytes + bytes / 4 + 255) / 256 * 256;
+        hipError_t e2 = hipMalloc((void**)&m->d_host_x, 3 * cap);
+        if (e2 != hipSuccess) { m->d_host_x = nullptr; return fail(CF_ERR_NOMEM, "cf_infer_host: hipMalloc failed"); }
+        m->d_host_p = m->d_host_x + cap / sizeof(float);
         m->host_stage_bytes = cap;
     }
-    float *dx = m->d_host_x, *dp = m->d_host_p;
+    float *dx = m->d_host_x, *dp = m->d_host_p, *dl = m->d_host_p + m->host_stage_bytes / sizeof(float);
     hipError_t e = hipSuccess;
     int rc = CF_OK;
     if ((e = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
-    if (rc == CF_OK) rc = cf_infer(m, dx, n_windows, dp, nullptr);
+    if (rc == CF_OK) rc = cf_infer_logits(m, dx, n_windows, probs ? dp : nullptr, logits ? dl : nullptr, nullptr);
     if (rc == CF_OK && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
-    if (rc == CF_OK && m->h_err && *m->h_err) rc = fail(CF_ERR_HIP, "fused GRU launch timed out waiting for a producer workgroup");
-    if (rc == CF_OK && (e = hipMemcpy(probs, dp, bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
+    if (rc == CF_OK) rc = cf_check_error(m);
+    if (rc == CF_OK && probs && (e = hipMemcpy(probs, dp, bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
+    if (rc == CF_OK && logits && (e = hipMemcpy(logits, dl, bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(CF_ERR_HIP, hipGetErrorString(e));
     return rc;
+}
+
+extern "C" int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, float* probs) {
+    if (n_windows > 0 && !probs) return fail(CF_ERR_INVALID, "cf_infer_host: null buffer");
+    return cf_infer_host_logits(m, x, n_windows, probs, nullptr);
 }
 
 extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets, const int64_t* read_lengths,

@@ -63,18 +63,37 @@ class HipEngine(object):
             raise ValueError("input must be [n_windows, %d(, 1)], got %s" % (WINDOW, tuple(shape)))
         return int(shape[0])
 
-    def infer_host(self, x):
-        """numpy [N,35(,1)] any float dtype -> numpy float32 [N*35] (H2D/D2H inside)."""
+    def infer_host(self, x, return_logits=False):
+        """numpy [N,35(,1)] any float dtype -> numpy float32 [N*35] (H2D/D2H inside).
+
+        ``return_logits=True`` -> (probs, logits): the pre-sigmoid values of rnn_class.py:178-183."""
         x = np.asarray(x)
         n = self._check_windows(x.shape)
         x32 = np.ascontiguousarray(x.reshape(n, WINDOW), dtype=np.float32)
         out = np.empty(n * WINDOW, dtype=np.float32)
+        if return_logits:
+            logits = np.empty(n * WINDOW, dtype=np.float32)
+            N.check(self._lib.cf_infer_host_logits(self._handle, x32.ctypes.data_as(C.c_void_p), n,
+                                                   out.ctypes.data_as(C.c_void_p), logits.ctypes.data_as(C.c_void_p)))
+            return out, logits
         N.check(self._lib.cf_infer_host(self._handle, x32.ctypes.data_as(C.c_void_p), n,
                                         out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def infer_device(self, x, out=None, stream=None):
-        """torch CUDA float32 tensor [N,35(,1)] -> torch CUDA float32 [N*35], async on the stream."""
+    def check_error(self):
+        """Raise if an earlier asynchronous launch of this model reported a device-side error (call after a sync)."""
+        N.check(self._lib.cf_check_error(self._handle))
+
+    def launch_regimes(self):
+        """Switch points of the launcher (windows): dict(n_cu, hoist_max, coop_max, fuse_auto_min)."""
+        out = (C.c_int64 * 4)()
+        N.check(self._lib.cf_launch_regimes(self._handle, out))
+        return dict(n_cu=int(out[0]), hoist_max=int(out[1]), coop_max=int(out[2]), fuse_auto_min=int(out[3]))
+
+    def infer_device(self, x, out=None, stream=None, logits=None):
+        """torch CUDA float32 tensor [N,35(,1)] -> torch CUDA float32 [N*35], async on the stream.
+
+        ``logits``: optional float32 CUDA tensor of N*35 elements that receives the pre-sigmoid values."""
         import torch
         if not x.is_cuda or x.dtype != torch.float32:
             raise ValueError("infer_device needs a float32 CUDA tensor")
@@ -88,6 +107,12 @@ class HipEngine(object):
             raise ValueError("out must be a contiguous float32 tensor of %d elements" % (n * WINDOW))
         if stream is None:
             stream = torch.cuda.current_stream(x.device)
+        if logits is not None:
+            if logits.numel() != n * WINDOW or logits.dtype != torch.float32 or not logits.is_contiguous() or not logits.is_cuda:
+                raise ValueError("logits must be a contiguous float32 CUDA tensor of %d elements" % (n * WINDOW))
+            N.check(self._lib.cf_infer_logits(self._handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(logits.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            return out
         N.check(self._lib.cf_infer(self._handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(out.data_ptr()),
                                    C.c_void_p(stream.cuda_stream)))
         return out
@@ -136,7 +161,8 @@ class HipEngine(object):
         N.check(self._lib.cf_spans(self._handle, C.c_void_p(labels.data_ptr()), total, int(max_runs),
                                    C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()),
                                    C.c_void_p(counts.data_ptr()), C.c_void_p(stream.cuda_stream)))
-        n_s, n_e = (int(v) for v in counts.cpu().tolist())
+        n_s, n_e = (int(v) for v in counts.cpu().tolist())      # synchronises the stream
+        self.check_error()                                        # the labels came from asynchronous launches
         if n_s != n_e:
             raise RuntimeError("cf_spans: %d run starts but %d run ends" % (n_s, n_e))
         if n_s > max_runs:

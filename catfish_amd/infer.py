@@ -26,20 +26,24 @@ def normalize_raw_signal(raw, norm_method):
     return (raw - shift) / scale
 
 
+def _trimmed_fast5_signal(fast5_file):
+    """infer.py:87-90: the raw DAC samples of the single read after the leader (``first_sample_template``)."""
+    first_sample = fast5_file["Analyses/Segmentation_000/Summary/segmentation"].attrs["first_sample_template"]
+    read_name = fast5_file["Raw/Reads/"].visit(str)
+    raw_signal = fast5_file["Raw/Reads/" + read_name + "/Signal"][()]
+    return raw_signal[first_sample:]
+
+
 def process_signal(fast5_file, normalization="median"):
     """infer.py:77-93: trim the leader (``first_sample_template``) and normalise.
 
     ``fast5_file`` is an open h5py.File, exactly as in the reference.
     """
-    first_sample = fast5_file["Analyses/Segmentation_000/Summary/segmentation"].attrs["first_sample_template"]
-    read_name = fast5_file["Raw/Reads/"].visit(str)
-    raw_signal = fast5_file["Raw/Reads/" + read_name + "/Signal"][()]
-    raw_signal = raw_signal[first_sample:]
-    return normalize_raw_signal(raw_signal, normalization)
+    return normalize_raw_signal(_trimmed_fast5_signal(fast5_file), normalization)
 
 
-def load_raw(path):
-    """Raw DAC samples of one read, already trimmed and normalised.
+def load_dac(path):
+    """Raw samples of one read after the leader trim, NOT normalised (what the device ingest path uploads).
 
     ``.fast5`` needs h5py (reference behaviour, infer.py:27-29); because h5py/libhdf5 are not
     part of the MI355X image, ``.npy`` (int16 DAC after the leader trim), ``.npz`` (key ``raw``
@@ -63,8 +67,23 @@ def load_raw(path):
             raise ImportError("reading %s needs h5py, which is not installed; convert the read to "
                               ".npy/.npz/.bin (int16 DAC samples)" % path)
         with h5py.File(path, "r") as fast5:
-            return process_signal(fast5)
-    return normalize_raw_signal(np.asarray(raw).reshape(-1), "median")
+            raw = _trimmed_fast5_signal(fast5)
+    return np.asarray(raw).reshape(-1)
+
+
+def is_dac(raw):
+    """True when ``raw`` can go up as int16 DAC codes unchanged (the device normalisation is exact on those)."""
+    raw = np.asarray(raw)
+    if raw.dtype == np.int16:
+        return True
+    if raw.dtype.kind in "iu" and raw.size:
+        return int(raw.min()) >= -32768 and int(raw.max()) <= 32767
+    return raw.dtype.kind in "iu"
+
+
+def load_raw(path):
+    """One read, trimmed and normalised (process_signal's result for any of ``load_dac``'s formats)."""
+    return normalize_raw_signal(load_dac(path), "median")
 
 
 def padding_size_for(length, window_size=WINDOW_SIZE):

@@ -49,7 +49,13 @@ class ReadPipeline(object):
         lengths = np.array([len(r) for r in dac_reads], dtype=np.int64)
         total = int(lengths.sum())
         if total > self.cap:
-            raise ValueError("batch of %d samples exceeds max_samples_per_batch=%d" % (total, self.cap))
+            if len(dac_reads) > 1:
+                raise ValueError("batch of %d samples exceeds max_samples_per_batch=%d" % (total, self.cap))
+            # a single read longer than the batch size: grow the pinned staging buffers once
+            for ev in self.stage_free:
+                ev.synchronize()
+            self.cap = total
+            self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(2)]
         dac_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
         np.cumsum(lengths, out=dac_off[1:])
         n_win = np.array([(int(n) + padding_size_for(int(n))) // WINDOW_SIZE for n in lengths], dtype=np.int64)
@@ -116,6 +122,7 @@ class ReadPipeline(object):
         ``as_lists=False`` skips the per-read Python lists and returns the span table as arrays
         ``(read_index, start - 11, end + 16, read_lengths)`` (what a high-rate consumer wants)."""
         t.done.synchronize()
+        self.eng.check_error()                                   # asynchronous launches of this batch: device-side errors are sticky
         n_s, n_e = (int(v) for v in t.counts_h.tolist())
         if n_s != n_e or n_s > t.max_runs:
             raise RuntimeError("cf_spans returned %d starts / %d ends (capacity %d)" % (n_s, n_e, t.max_runs))

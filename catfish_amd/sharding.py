@@ -6,8 +6,21 @@ reference's sequential per-file loop partitions into disjoint shards.  Each rank
 shard on its own MI355X with its own copy of the 0.79 MB weights; the only communication is
 the final HOST gather of the per-read results to rank 0 (pickled Python objects over a gloo
 group) -- RCCL/xGMI is never on the critical path.
+
+Entry points
+    ``run_sharded_indexed``   the core: shard item INDICES by cost, run a callable on this rank's
+                              indices, gather on rank 0 (a rank never touches another rank's items)
+    ``run_sharded``           the same for a list of in-memory signals
+    ``infer_reads_sharded``   product path: this rank's reads stream through one HipEngine's
+                              ``ReadPipeline`` (int16 DAC up, spans down), results gathered on rank 0
+    ``infer_files_sharded``   the reference's per-file loop (catfish/catfish:50-56): files shard by size,
+                              every rank loads only its own files, a bounded batch at a time
+Launch: ``python -m torch.distributed.run --nproc-per-node N -m catfish_amd.cli -i ... -s ...`` (or
+``catfish_amd.cli --gpus N``, which starts that launcher as a child process before any GPU call).
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -18,15 +31,15 @@ def windows_of(length, window=WINDOW_SIZE):
     return (int(length) + padding_size_for(int(length), window)) // window
 
 
-def shard_reads(lengths, world_size):
-    """Greedy longest-processing-time partition of read indices by window count.
+def shard_costs(costs, world_size):
+    """Greedy longest-processing-time partition of item indices by cost.
 
-    Returns ``world_size`` lists of indices (each ascending).  Equal-length reads degenerate to
-    near-equal contiguous-count shards.
+    Returns ``world_size`` lists of indices (each ascending).  Equal costs degenerate to a
+    round-robin deal.
     """
     if world_size < 1:
         raise ValueError("world_size must be >= 1")
-    cost = np.array([windows_of(n) for n in lengths], dtype=np.int64)
+    cost = np.asarray(costs, dtype=np.int64)
     order = np.argsort(-cost, kind="stable")
     load = np.zeros(world_size, dtype=np.int64)
     shards = [[] for _ in range(world_size)]
@@ -37,12 +50,49 @@ def shard_reads(lengths, world_size):
     return [sorted(s) for s in shards]
 
 
-def run_sharded(signals, infer_fn, rank=None, world_size=None, gather_group=None):
-    """Run ``infer_fn(list of signals) -> list of results`` on this rank's shard and gather on rank 0.
+def shard_reads(lengths, world_size):
+    """LPT partition of reads by window count (the unit of device work)."""
+    return shard_costs([windows_of(n) for n in lengths], world_size)
 
-    All ranks pass the same ``signals`` list (or at least the same lengths: a rank only touches
-    its own shard's entries).  Returns the full result list in input order on rank 0 and None on
-    the other ranks.  Without an initialised process group it simply runs everything locally.
+
+def dist_env():
+    """(rank, world_size, local_rank) from the launcher's environment (torch.distributed.run); 0, 1, 0 without one."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_host_group():
+    """Initialise the process group of a sharded job when the launcher started more than one rank.
+
+    gloo only: the data path has no collective, the group serves the final host gather (and barriers).
+    Returns True when a group was created here (the caller then destroys it).
+    """
+    import torch.distributed as dist
+    _rank, world, _local = dist_env()
+    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    return True
+
+
+def host_gather_group():
+    """A gloo group for the final host gather (object pickles travel over TCP/shared memory, never
+    through RCCL); falls back to the default group when that already is gloo."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend() == "gloo":
+        return None
+    return dist.new_group(backend="gloo")
+
+
+def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group=None):
+    """Shard ``len(costs)`` items by cost, run ``work_fn(list of my indices) -> list of results`` on this
+    rank's shard, gather on rank 0.
+
+    Returns the full result list in item order on rank 0 and None on the other ranks.  Without an
+    initialised process group it simply runs everything locally.
     """
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -50,13 +100,14 @@ def run_sharded(signals, infer_fn, rank=None, world_size=None, gather_group=None
         rank = dist.get_rank() if distributed else 0
     if world_size is None:
         world_size = dist.get_world_size() if distributed else 1
-    shards = shard_reads([len(s) if s is not None else 0 for s in signals], world_size)
+    n_items = len(costs)
+    shards = shard_costs(costs, world_size)
     mine = shards[rank]
-    local = infer_fn([signals[i] for i in mine]) if mine else []
+    local = list(work_fn(mine)) if mine else []
     if len(local) != len(mine):
-        raise RuntimeError("infer_fn returned %d results for %d reads" % (len(local), len(mine)))
+        raise RuntimeError("work_fn returned %d results for %d items" % (len(local), len(mine)))
     if world_size == 1:
-        out = [None] * len(signals)
+        out = [None] * n_items
         for i, res in zip(mine, local):
             out[i] = res
         return out
@@ -66,17 +117,139 @@ def run_sharded(signals, infer_fn, rank=None, world_size=None, gather_group=None
     dist.gather_object(list(zip(mine, local)), gathered, dst=0, group=gather_group)
     if rank != 0:
         return None
-    out = [None] * len(signals)
+    out = [None] * n_items
     for part in gathered:
         for i, res in part:
             out[i] = res
     return out
 
 
-def host_gather_group():
-    """A gloo group for the final host gather (object pickles travel over TCP/shared memory, never
-    through RCCL); falls back to the default group when that already is gloo."""
-    import torch.distributed as dist
-    if dist.get_backend() == "gloo":
-        return None
-    return dist.new_group(backend="gloo")
+def run_sharded(signals, infer_fn, rank=None, world_size=None, gather_group=None):
+    """Run ``infer_fn(list of signals) -> list of results`` on this rank's shard and gather on rank 0.
+
+    All ranks pass the same ``signals`` list (or at least the same lengths: a rank only touches
+    its own shard's entries).
+    """
+    costs = [windows_of(len(s)) if s is not None else 0 for s in signals]
+    return run_sharded_indexed(costs, lambda mine: infer_fn([signals[i] for i in mine]),
+                               rank=rank, world_size=world_size, gather_group=gather_group)
+
+
+# --------------------------------------------------------------------------- product path
+def _batches_by_samples(indices, lengths, max_samples):
+    """Consecutive groups of ``indices`` holding at most ``max_samples`` samples each (at least one read)."""
+    cur, tot = [], 0
+    for i in indices:
+        n = int(lengths[i])
+        if cur and tot + n > max_samples:
+            yield cur
+            cur, tot = [], 0
+        cur.append(i)
+        tot += n
+    if cur:
+        yield cur
+
+
+class EngineBatchRunner(object):
+    """This rank's device work: batches of raw reads through ONE engine.
+
+    int16 DAC reads take the streaming ``ReadPipeline`` (2 B/sample up, device median/MAD normalisation,
+    double-buffered); anything else (float signals, e.g. an already normalised trace) is normalised on the
+    host like ``infer.process_signal`` and goes through ``batching.infer_reads``.
+    """
+
+    def __init__(self, model, max_samples_per_batch, threshold=0.5, min_run=15):
+        from .pipeline import ReadPipeline
+        self.engine = model.engine if hasattr(model, "engine") else model
+        if self.engine is None:
+            raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")
+        self.max_samples = int(max_samples_per_batch)
+        self.threshold, self.min_run = threshold, min_run
+        self.pipe = ReadPipeline(self.engine, self.max_samples, threshold=threshold, min_run=min_run)
+
+    def run(self, batches):
+        """``batches``: iterable of lists of raw reads -> yields [(spans, length)] per batch, in order."""
+        from . import batching
+        from .infer import is_dac, normalize_raw_signal
+        pending = None           # (ticket, host-path results or None)
+        for reads in batches:
+            if all(is_dac(r) for r in reads):
+                item = (self.pipe.submit([np.ascontiguousarray(r, dtype=np.int16) for r in reads]), None)
+            else:
+                normed = [normalize_raw_signal(np.asarray(r), "median") for r in reads]
+                max_windows = max(1, self.max_samples // WINDOW_SIZE)
+                item = (None, batching.infer_reads(self.engine, normed, max_windows=max_windows,
+                                                   threshold=self.threshold, min_run=self.min_run))
+            if pending is not None:
+                yield self._finish(pending)
+            pending = item
+        if pending is not None:
+            yield self._finish(pending)
+
+    def _finish(self, item):
+        ticket, host_res = item
+        return self.pipe.collect(ticket) if ticket is not None else host_res
+
+
+def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_per_batch=None, batch_runner=None,
+                        rank=None, world_size=None, gather_group=None, costs=None):
+    """Homopolymer spans of many reads, sharded over the ranks of the job; rank 0 gets ``[(spans, length)]``
+    in input order, the other ranks get None.
+
+    ``reads``      list of raw reads (int16 DAC arrays) -- or of anything ``load_fn(item)`` turns into one
+                   (e.g. file paths: a rank only loads its own shard, one bounded batch at a time)
+    ``lengths``    per-read sample counts when known up front (default ``len(read)``); with ``load_fn`` and
+                   no lengths the batches are cut after loading
+    ``costs``      sharding weights (default: window counts from ``lengths``)
+    ``batch_runner`` object with ``run(iterable of read batches) -> iterable of per-batch result lists``
+                   (default: ``EngineBatchRunner(model)`` = the HIP engine of this rank)
+    """
+    n = len(reads)
+    if lengths is None and load_fn is None:
+        lengths = [len(r) for r in reads]
+    if costs is None:
+        if lengths is None:
+            raise ValueError("infer_reads_sharded: pass lengths or costs together with load_fn")
+        costs = [windows_of(x) for x in lengths]
+    if max_samples_per_batch is None:
+        max_samples_per_batch = 32768 * WINDOW_SIZE
+    if n == 0:
+        return [] if (dist_env()[0] if rank is None else rank) == 0 else None
+
+    def work(mine):
+        runner = batch_runner if batch_runner is not None else EngineBatchRunner(model, max_samples_per_batch)
+
+        def batches():
+            if lengths is not None:
+                for idx in _batches_by_samples(mine, lengths, max_samples_per_batch):
+                    yield [reads[i] if load_fn is None else load_fn(reads[i]) for i in idx]
+            else:                       # lengths unknown until loaded: cut a batch when the next read would not fit
+                cur, tot = [], 0
+                for i in mine:
+                    r = load_fn(reads[i])
+                    if cur and tot + len(r) > max_samples_per_batch:
+                        yield cur
+                        cur, tot = [], 0
+                    cur.append(r)
+                    tot += len(r)
+                if cur:
+                    yield cur
+        out = []
+        for res in runner.run(batches()):
+            out.extend(res)
+        return out
+
+    return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group)
+
+
+def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=None, rank=None, world_size=None,
+                        gather_group=None):
+    """The reference's per-file loop (catfish/catfish:50-56), sharded: files are dealt to ranks by size on disk
+    (a proxy of the sample count that needs no read), every rank loads only its own files through
+    ``infer.load_dac`` -- one batch at a time, so host memory does not grow with the directory -- and rank 0
+    receives ``[(spans, read length)]`` in the order of ``paths``."""
+    from .infer import load_dac
+    costs = [max(1, os.path.getsize(p)) if os.path.exists(p) else 1 for p in paths]
+    return infer_reads_sharded(model, list(paths), lengths=None, load_fn=load_dac, costs=costs,
+                               max_samples_per_batch=max_samples_per_batch, batch_runner=batch_runner,
+                               rank=rank, world_size=world_size, gather_group=gather_group)

@@ -111,6 +111,29 @@ int cf_infer(cf_model* m, const float* x, int64_t n_windows, float* probs, void*
 /* Same with host buffers (synchronous; H2D / D2H included). */
 int cf_infer_host(cf_model* m, const float* x, int64_t n_windows, float* probs);
 
+/* The same two calls with the pre-sigmoid logits as a second output (``self.logits`` of
+ * RNN.output_layer, catfish/models/rnn_class.py:178-183): the reference evaluates its validation
+ * loss on the logits (tf.losses.sigmoid_cross_entropy, rnn_class.py:74-79,236-237), which the
+ * saturated fp32 probabilities cannot reproduce.  probs or logits may be NULL (not both). */
+int cf_infer_logits(cf_model* m, const float* x, int64_t n_windows, float* probs, float* logits, void* stream);
+int cf_infer_host_logits(cf_model* m, const float* x, int64_t n_windows, float* probs, float* logits);
+
+/* Sticky device-side error of earlier asynchronous launches on this model (today: a bounded wait of the
+ * fused biGRU launch that timed out, which invalidates that launch's results).  Call it after
+ * synchronising the stream a cf_infer was queued on; CF_OK, or CF_ERR_HIP with the message in
+ * cf_last_error().  cf_infer / cf_infer_host also refuse to run while it is set. */
+int cf_check_error(cf_model* m);
+
+/* Launch-regime switch points of this model on its device, for callers and tests that need to know which
+ * kernels a call of n_windows uses (all in windows):
+ *   out[0] = CUs of the device
+ *   out[1] = largest call whose biGRU x projection is hoisted onto the idle CUs (latency mode, fp32)
+ *   out[2] = largest call served by the cooperative latency-mode biGRU kernels (fp32); larger calls use the
+ *            throughput kernels (one wave per tile)
+ *   out[3] = smallest call whose biGRU layers go out as ONE fused launch when fuse_layers = 0 (auto);
+ *            0 when this model never fuses */
+int cf_launch_regimes(const cf_model* m, int64_t out[4]);
+
 /* Read-level post-processing on device, replacing class_from_threshold +
  * correct_short (catfish/infer.py:128-138,174-198).  Reads are packed back to
  * back INCLUDING their zero padding (infer.py:31-38): read r owns samples

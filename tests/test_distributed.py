@@ -63,6 +63,93 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert (tmp_path / "ok").exists()
 
 
+class _OracleBatchRunner(object):
+    """Stand-in for sharding.EngineBatchRunner on a box without a GPU: the same interface (an iterable of raw-read
+    batches in, per-batch [(spans, length)] out), backed by the CPU oracle."""
+
+    def __init__(self, weights):
+        self.w = weights
+        self.batches = []
+
+    def run(self, batches):
+        from oracle import catfish_oracle as oracle
+        for reads in batches:
+            self.batches.append([len(r) for r in reads])
+            out = []
+            for r in reads:
+                spans, n, _ = oracle.infer_read(oracle.normalize_raw_signal(np.asarray(r)), self.w, np.float32)
+                out.append((spans, n))
+            yield out
+
+
+def _runner_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from catfish_amd import sharding
+    from oracle import catfish_oracle as oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    assert sharding.dist_env() == (rank, world, rank)
+    assert sharding.init_host_group()                  # the product's own group set-up (gloo)
+    try:
+        w = oracle.random_weights(seed=3)
+        lens = [36, 700, 35, 140, 999, 70, 512, 64, 300, 2000, 1]
+        dacs = [oracle.synthetic_dac(1, max(n, 2), seed=40 + i)[0][:n] for i, n in enumerate(lens)]
+        paths = []
+        for i, d in enumerate(dacs):
+            p = os.path.join(tmpdir, "read%02d.npy" % i)
+            if rank == 0:
+                np.save(p, d)
+            paths.append(p)
+        dist.barrier()
+        fake = _OracleBatchRunner(w)
+        # in-memory reads, batches bounded by samples
+        res = sharding.infer_reads_sharded(None, dacs, max_samples_per_batch=1200, batch_runner=fake,
+                                           gather_group=sharding.host_gather_group())
+        mine = sharding.shard_reads(lens, world)[rank]
+        assert sorted(sum(fake.batches, [])) == sorted(lens[i] for i in mine)      # this rank ran its own shard only
+        assert all(sum(b) <= 1200 or len(b) == 1 for b in fake.batches)
+        # files: every rank loads only its own shard
+        fake2 = _OracleBatchRunner(w)
+        res_f = sharding.infer_files_sharded(None, paths, max_samples_per_batch=1200, batch_runner=fake2)
+        assert 0 < len(sum(fake2.batches, [])) < len(lens)
+        if rank == 0:
+            want = [oracle.infer_read(oracle.normalize_raw_signal(d), w, np.float32)[:2] for d in dacs]
+            want = [(s, n) for s, n in want]
+            assert res == want and res_f == want
+            open(os.path.join(tmpdir, "ok2"), "w").write("ok")
+        else:
+            assert res is None and res_f is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_runner_with_fake_engine(tmp_path):
+    """The product's sharded runner (what catfish_amd.cli calls) on two gloo ranks; the per-rank engine is replaced
+    by an oracle-backed batch runner because this box has no GPU (tests/test_gpu_pipeline.py drives the real one)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_runner_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok2").exists()
+
+
+def test_shard_costs_balances_and_covers():
+    sys.path.insert(0, ROOT)
+    from catfish_amd import sharding
+    rng = np.random.default_rng(5)
+    costs = rng.integers(1, 500, size=200)
+    for world in (1, 2, 3, 8):
+        shards = sharding.shard_costs(costs, world)
+        assert sorted(sum(shards, [])) == list(range(200))
+        loads = [int(costs[s].sum()) for s in shards]
+        assert max(loads) - min(loads) <= int(costs.max())          # LPT bound
+    assert sharding.shard_costs([5, 5, 5, 5], 2) == [[0, 2], [1, 3]]
+    with pytest.raises(ValueError):
+        sharding.shard_costs([1], 0)
+
+
 def test_single_process_run_sharded_without_process_group():
     sys.path.insert(0, ROOT)
     from catfish_amd import sharding

@@ -420,3 +420,82 @@ def test_cli_end_to_end(tmp_path, ckpt_weights, monkeypatch):
     # second run into the same directory fails like the reference (os.makedirs on an existing TEMP/HP)
     res2 = CliRunner().invoke(cli._build_click_main(), ["-i", str(reads), "-s", str(tmp_path / "out")])
     assert res2.exit_code != 0
+
+
+def _write_model_dir(tmp_path, ckpt_weights):
+    from catfish_amd import checkpoint
+    net = tmp_path / "ResNetRNN"
+    (net / "checkpoints").mkdir(parents=True)
+    (net / "ResNetRNN.txt").write_text("MODEL TYPE: ResNet-RNN\n\nbatch_size: 256\noptimizer_choice: RMSProp\n"
+                                       "learning_rate: 0.001\nlayer_size: 64\nn_layers: 3\nkeep_prob: 0.8\n"
+                                       "layer_size_res: 32\nn_layers_res: 2\n")
+    checkpoint.write_checkpoint(str(net / "checkpoints" / "ckpnt-30000"), ckpt_weights)
+    return net
+
+
+def test_sharded_runner_world1_real_engine(model, ckpt_weights, tmp_path):
+    """BASELINE configs[2] plumbing at world_size 1: the sharded runner (catfish/catfish:50-56 partitioned) drives the
+    REAL HIP engine through the streaming pipeline and equals the per-read oracle; float inputs take the host
+    normalisation branch."""
+    from catfish_amd import sharding
+    lens = [4096, 36, 700, 35, 140, 999, 70, 512, 64, 300, 2000, 3333, 37, 4096]
+    dacs = [oracle.synthetic_dac(1, max(n, 2), seed=900 + i)[0][:n] for i, n in enumerate(lens)]
+    want = []
+    for d in dacs:
+        spans, n, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
+        want.append((spans, n))
+    got = sharding.infer_reads_sharded(model, dacs, max_samples_per_batch=6000)          # several batches, one oversize read
+    assert got == want
+    paths = []
+    for i, d in enumerate(dacs):
+        p = tmp_path / ("r%02d.npy" % i)
+        np.save(p, d)
+        paths.append(str(p))
+    assert sharding.infer_files_sharded(model, paths, max_samples_per_batch=6000) == want
+    # explicit rank of a 3-rank job without a process group: only that shard is touched, gather is refused
+    with pytest.raises(RuntimeError):
+        sharding.infer_reads_sharded(model, dacs, rank=1, world_size=3)
+    # float (already calibrated) traces: host normalisation branch
+    flt = [d.astype(np.float64) * 0.25 + 3.0 for d in dacs[:4]]
+    got_f = sharding.infer_reads_sharded(model, flt)
+    for (spans, n), f in zip(got_f, flt):
+        w_spans, w_n, _ = oracle.infer_read(oracle.normalize_raw_signal(f), ckpt_weights, np.float32)
+        assert (spans, n) == (w_spans, w_n)
+
+
+@pytest.mark.timeout(600)
+def test_cli_two_ranks_share_one_gpu(tmp_path, ckpt_weights):
+    """The multi-GPU entry point end to end: `torch.distributed.run --nproc-per-node 2 -m catfish_amd.cli` (what
+    `catfish --gpus 2` starts), both ranks pinned to cuda:0 by CATFISH_DEVICE because this box has one GPU.
+    Rank 0 gathers over gloo and writes the chunk coordinates; they must equal the per-read oracle."""
+    import json
+    import subprocess
+    import sys
+    from catfish_amd import cli
+    from conftest import ROOT
+    _write_model_dir(tmp_path, ckpt_weights)
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    dacs = {}
+    for i, n in enumerate((4096, 2500, 700, 36, 3000, 1500, 5000)):
+        d = oracle.synthetic_dac(1, n, seed=700 + i)[0]
+        np.save(reads / ("read%d.npy" % i), d)
+        dacs["read%d.npy" % i] = d
+    env = dict(os.environ, CATFISH_DEVICE="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "-m", "catfish_amd.cli", "-i", str(reads), "-s", str(tmp_path / "out"), "-c", "300"]
+    res = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True, timeout=500)
+    assert res.returncode == 0, res.stdout[-3000:]
+    hp = json.load(open(tmp_path / "out" / "TEMP" / "hp_positions.json"))
+    nonhp = json.load(open(tmp_path / "out" / "TEMP" / "nonhp_positions.json"))
+    assert set(nonhp) == set(dacs)
+    for name, d in dacs.items():
+        spans, length, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
+        merged, non = cli.chunks_of_read([list(s) for s in spans], length, 300)
+        if merged is not None:
+            assert hp[name] == merged
+            assert nonhp[name] == non
+        else:
+            assert name not in hp

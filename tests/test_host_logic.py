@@ -71,7 +71,10 @@ def test_cli_tail_matches_reference(golden):
 def test_cli_options_match_reference():
     main = cli._build_click_main()
     opts = {o.name: o for o in main.params}
-    assert set(opts) == {"input_dir", "split_dir", "chunk_size"}
+    # the reference's three options, unchanged; --gpus / --network-path / --precision are MI355X additions
+    assert {"input_dir", "split_dir", "chunk_size"} <= set(opts)
+    assert set(opts) - {"input_dir", "split_dir", "chunk_size"} == {"gpus", "network_path", "precision"}
+    assert opts["gpus"].default == 1 and opts["network_path"].default == "ResNetRNN" and opts["precision"].default == "fp32"
     assert opts["input_dir"].opts == ["--input-dir", "-i"]
     assert opts["split_dir"].opts == ["--split-dir", "-s"]
     assert opts["chunk_size"].opts == ["--chunk-size", "-c"] and opts["chunk_size"].default == 1000

@@ -4,11 +4,14 @@
 // Roles: 0 idle | 1 f32 MFMA 16x16x4 | 2 VALU fma | 3 transcendental (exp2+rcp) | 4 bf16 MFMA 32x32x16
 //        5 one wave interleaving bf16 MFMA with 6 VALU fma each | 6 same with f32 MFMA
 //        7 one wave interleaving bf16 MFMA with 2 transcendentals + 2 fma each | 8 same with f32 MFMA
+//        9 packed-fp32 fma (v_pk_fma_f32) only | 10 bf16 MFMA with 2 transcendentals + 1 v_pk_fma_f32 each
+//        11 bf16 MFMA with 4 transcendentals + 2 fma each (the VALU-heavy mix of the bf16 biGRU step)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int ROLE>
 __device__ __forceinline__ float work(float r, int iters) {
@@ -42,7 +45,17 @@ __device__ __forceinline__ float work(float r, int iters) {
                 for (int i = 0; i < 16; ++i) a[i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a[i]));
         }
         for (int i = 0; i < 16; ++i) r += a[i];
-    } else if constexpr (ROLE == 4 || ROLE == 5 || ROLE == 7) {
+    } else if constexpr (ROLE == 9) {
+        f32x2 a[8];
+        for (int i = 0; i < 8; ++i) a[i] = (f32x2){r + i, r - i};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], (f32x2){1.0001f, 1.0001f}, (f32x2){0.5f, 0.5f});
+        }
+        for (int i = 0; i < 8; ++i) r += a[i].x + a[i].y;
+    } else if constexpr (ROLE == 4 || ROLE == 5 || ROLE == 7 || ROLE == 10 || ROLE == 11) {
         f32x16 acc[4];
         bf16x8 a, b;
         float v[12];
@@ -63,6 +76,18 @@ __device__ __forceinline__ float work(float r, int iters) {
                         v[2 * i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[2 * i]));
                         v[2 * i + 1] = __builtin_fmaf(v[2 * i + 1], 1.0001f, 0.5f);
                         v[8 + i] = __builtin_fmaf(v[8 + i], 1.0001f, 0.5f);
+                    }
+                    if constexpr (ROLE == 10) {
+                        v[2 * i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[2 * i]));
+                        f32x2 pk = {v[2 * i + 1], v[8 + i]};
+                        pk = __builtin_elementwise_fma(pk, (f32x2){1.0001f, 1.0001f}, (f32x2){0.5f, 0.5f});
+                        v[2 * i + 1] = pk.x; v[8 + i] = pk.y;
+                    }
+                    if constexpr (ROLE == 11) {
+                        v[2 * i] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[2 * i]));
+                        v[2 * i + 1] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[2 * i + 1]));
+                        v[8 + i] = __builtin_fmaf(v[8 + i], 1.0001f, 0.5f);
+                        v[8 + (i ^ 1)] = __builtin_fmaf(v[8 + (i ^ 1)], 1.0001f, 0.5f);
                     }
                 }
         }
@@ -106,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
     out[blockIdx.x * 512 + threadIdx.x] = r;
 }
 
-static const char* names[] = {"idle", "f32mfma", "valu", "trans", "bf16mfma", "bf16mfma+6fma", "f32mfma+6fma", "bf16mfma+trans", "f32mfma+trans"};
+static const char* names[] = {"idle", "f32mfma", "valu", "trans", "bf16mfma", "bf16mfma+6fma", "f32mfma+6fma", "bf16mfma+trans", "f32mfma+trans", "pkfma", "bf16mfma+tr+pk", "bf16mfma+4tr"};
 
 template <int RA, int RB>
 void run(float* d) {
@@ -130,5 +155,6 @@ int main() {
     run<1, 1>(d); run<2, 2>(d); run<3, 3>(d); run<4, 4>(d);
     run<1, 2>(d); run<2, 1>(d); run<1, 3>(d); run<4, 2>(d); run<2, 4>(d); run<4, 3>(d); run<3, 4>(d);
     run<5, 0>(d); run<6, 0>(d); run<7, 0>(d); run<8, 0>(d); run<5, 5>(d); run<7, 7>(d); run<8, 8>(d);
+    run<9, 0>(d); run<9, 9>(d); run<4, 9>(d); run<10, 0>(d); run<10, 10>(d); run<11, 0>(d); run<11, 11>(d);
     return 0;
 }
