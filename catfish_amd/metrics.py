@@ -1,4 +1,5 @@
-"""Confusion counts, mirror of reference catfish/metrics.py:3-36 (vectorised)."""
+"""Confusion counts and the scores derived from them -- mirror of reference catfish/metrics.py:3-36 and
+networks/trainingDB/metrics.py:40-63,117-135 (vectorised counting, same results)."""
 import numpy as np
 
 
@@ -17,3 +18,35 @@ def confusion_matrix(true_labels, predicted_labels):
     true_neg = int(np.count_nonzero((p == 0) & (t == 0)))
     false_neg = int(np.count_nonzero((p == 0) & (t != 0)))
     return true_pos, false_pos, true_neg, false_neg
+
+
+def precision_recall(true_pos, false_pos, false_neg):
+    """networks/trainingDB/metrics.py:40-55: an empty denominator gives 0 (with the reference's message)."""
+    try:
+        precision = true_pos / (true_pos + false_pos)
+    except ZeroDivisionError:
+        precision = 0
+        print("Precision could not be calculated.")
+    try:
+        recall = true_pos / (true_pos + false_neg)
+    except ZeroDivisionError:
+        recall = 0
+        print("Recall could not be calculated.")
+    return precision, recall
+
+
+def calculate_accuracy(true_pos, false_pos, true_neg, false_neg):
+    """networks/trainingDB/metrics.py:58-63."""
+    try:
+        return (true_pos + true_neg) / (true_pos + false_pos + true_neg + false_neg)
+    except ZeroDivisionError:
+        return 0
+
+
+def f1(precision, recall):
+    """networks/trainingDB/metrics.py:117-135: balanced F1 of one class, 0 when precision + recall = 0."""
+    try:
+        return 2 * (precision * recall) / (precision + recall)
+    except ZeroDivisionError:
+        print("Precision, recall or both are zero. Unable of calculating weighted F1.")
+        return 0

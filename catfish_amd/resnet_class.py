@@ -12,6 +12,11 @@ class ResNetRNN(RNN):
         self._model_type = self.network_type
         RNN.__init__(self, **kwargs)
 
+    def save_info(self):
+        """resnet_class.py:28-32: the RNN header plus the two residual-stack lines."""
+        RNN.save_info(self)
+        self._write_report("layer_size_res: {}\nn_layers_res: {}\n\n".format(self.layer_size_res, self.n_layers_res), "a")
+
     @property
     def model_type(self):
         return self._model_type

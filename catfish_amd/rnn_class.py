@@ -52,9 +52,12 @@ class RNN(object):
         self._engine_stale = False
         self.train_loss = None
         self.train_seed = kwargs.get("train_seed")
+        self._model_path = None
         if save:
-            raise NotImplementedError("save=True (TensorBoard/model directory bookkeeping, rnn_class.py:43-46) "
-                                      "belongs to the training stack, which is out of scope of this path")
+            # rnn_class.py:43-46: claim a fresh model directory and write the model report; the TensorBoard
+            # writer of the reference (:126-139) has no counterpart here (JSON logs instead)
+            self.model_path = self.model_type
+            self.save_info()
 
         # saving test performance (rnn_class.py:51-54)
         self.tp = 0
@@ -74,6 +77,31 @@ class RNN(object):
     @property
     def layer_size_res_(self):
         return 32
+
+    @property
+    def model_path(self):
+        return self._model_path
+
+    @model_path.setter
+    def model_path(self, model_type):
+        """rnn_class.py:100-118: the first free ``<dir>/<model_type>_<n>`` is created and becomes the model
+        directory.  The reference hard-codes its authors' scratch directory (:102) and keeps ``os.getcwd()`` as the
+        commented alternative (:103); here the parent is ``CATFISH_MODEL_DIR`` or the current directory."""
+        cur_dir = os.environ.get("CATFISH_MODEL_DIR") or os.getcwd()
+        number = 0
+        while True:
+            model_path = "{}/{}_{}".format(cur_dir, model_type, number)
+            if not os.path.isdir(model_path):
+                os.mkdir(model_path)
+                break
+            number += 1
+        print("\nSaving network checkpoints to", model_path, "\n")
+        self._model_path = model_path
+
+    def use_model_path(self, model_path):
+        """Adopt an existing model directory as ``model_path`` (no ``_<n>`` numbering), e.g. to continue a run."""
+        os.makedirs(model_path, exist_ok=True)
+        self._model_path = model_path
 
     # ------------------------------------------------------------------ weights
     def _load_engine(self, weights):
@@ -173,21 +201,30 @@ class RNN(object):
     def test_network(self, test_x, test_y, read_name, file_path, padding_size, threshold=0.5):
         """rnn_class.py:222-261: predictions + accuracy/loss + running confusion counters."""
         self._require_engine()
-        confidences = self.infer(test_x)
+        probs32, logits32 = self.engine.infer_host(np.asarray(test_x), return_logits=True)
+        confidences = np.reshape(probs32, (-1)).astype(float)
         pred_vals = (confidences >= threshold).astype(np.int64)
         test_labels = np.asarray(test_y).reshape(-1)
-        # accuracy: tf.equal(tf.round(p), y) (rnn_class.py:85-86); loss: mean sigmoid cross-entropy (:76-77)
+        # accuracy: tf.equal(tf.round(p), y) (rnn_class.py:85-86)
         test_acc = float(np.mean(np.round(confidences) == test_labels))
-        eps = np.finfo(np.float64).tiny
-        p = np.clip(confidences, eps, 1.0)
-        q = np.clip(1.0 - confidences, eps, 1.0)
-        test_loss = float(np.mean(-(test_labels * np.log(p) + (1.0 - test_labels) * np.log(q))))
+        # loss: tf.losses.sigmoid_cross_entropy evaluates the LOGITS (rnn_class.py:74-79):
+        # mean(max(z, 0) - z*y + log1p(exp(-|z|))); probabilities saturate in fp32 and cannot reproduce it
+        test_loss = sigmoid_cross_entropy_from_logits(logits32.astype(np.float64), test_labels)
         true_pos, false_pos, true_neg, false_neg = metrics.confusion_matrix(test_labels, pred_vals)
         self.tp += true_pos
         self.fp += false_pos
         self.tn += true_neg - padding_size
         self.fn += false_neg
         return test_acc, test_loss
+
+    def evaluate(self, set_x, set_y):
+        """``sess.run([self.accuracy, self.loss], ...)`` (networks/train_validate.py:162; rnn_class.py:74-88) on the
+        inference graph: (accuracy, loss) of one batch without touching the confusion counters."""
+        self._require_engine()
+        probs32, logits32 = self.engine.infer_host(np.asarray(set_x), return_logits=True)
+        labels = np.asarray(set_y).reshape(-1)
+        acc = float(np.mean(np.round(probs32.astype(float)) == labels))
+        return acc, sigmoid_cross_entropy_from_logits(logits32.astype(np.float64), labels)
 
     def train_network(self, train_x, train_y, step):
         """rnn_class.py:201-210: one optimizer step on a batch (PyTorch-ROCm autograd, TF update rules).
@@ -225,5 +262,40 @@ class RNN(object):
             fh.write('model_checkpoint_path: "ckpnt-%d"\nall_model_checkpoint_paths: "ckpnt-%d"\n' % (int(step), int(step)))
         return prefix
 
+    def save_network_to_model_path(self, step):
+        """networks/train_validate.py:154: ``saver.save(sess, model_path + "/checkpoints/ckpnt", global_step=step)``."""
+        if self.model_path is None:
+            raise RuntimeError("no model directory: construct the network with save=True or call use_model_path()")
+        path = os.path.join(self.model_path, "checkpoints")
+        os.makedirs(path, exist_ok=True)
+        return self.save_network(path, step)
+
+    def report_file(self):
+        """Where ``save_info`` writes: the reference names it ``<model_path>.txt`` (NEXT TO the model directory,
+        rnn_class.py:265); ``neural_network.load_network`` reads ``<network dir>/ResNetRNN.txt`` (neural_network.py:30),
+        which is how the authors shipped it (catfish/ResNetRNN/ResNetRNN.txt).  Both are written."""
+        return self.model_path + ".txt"
+
+    def _write_report(self, text, mode):
+        with open(self.report_file(), mode) as dest:
+            dest.write(text)
+        with open(os.path.join(self.model_path, "ResNetRNN.txt"), mode) as dest:
+            dest.write(text)
+
     def save_info(self):
-        raise NotImplementedError("save_info (rnn_class.py:264-270) belongs to the training stack")
+        """rnn_class.py:264-270: the model report header (``key: value`` lines retrieve_hyperparams parses)."""
+        if self.model_path is None:
+            raise RuntimeError("no model directory: construct the network with save=True or call use_model_path()")
+        self._write_report("MODEL TYPE: {}\n\n".format(self.model_type)
+                           + "batch_size: {}\noptimizer_choice: {}\nlearning_rate: {}\n".format(
+                               self.batch_size, self.optimizer_choice, self.learning_rate)
+                           + "layer_size: {}\nn_layers: {}\nkeep_prob: {}\n".format(
+                               self.layer_size, self.n_layers, self.keep_prob), "w")
+
+
+def sigmoid_cross_entropy_from_logits(logits, labels):
+    """tf.losses.sigmoid_cross_entropy with default weights and reduction (rnn_class.py:74-79): the mean over all
+    elements of ``max(z, 0) - z*y + log(1 + exp(-|z|))`` (TF's numerically stable form)."""
+    z = np.asarray(logits, dtype=np.float64).reshape(-1)
+    y = np.asarray(labels, dtype=np.float64).reshape(-1)
+    return float(np.mean(np.maximum(z, 0.0) - z * y + np.log1p(np.exp(-np.abs(z)))))

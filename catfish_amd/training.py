@@ -180,9 +180,21 @@ class TFOptimizer(object):
                     if name in state:
                         slot[k].copy_(torch.as_tensor(np.asarray(state[name]), dtype=p.dtype).reshape(p.shape))
             if self.choice == "Adam":
-                for name in ("optimizer/beta1_power", "beta1_power"):
-                    if name in state and 0.0 < float(state[name]) < 1.0:
-                        self.t.fill_(round(np.log(float(state[name])) / np.log(0.9)) - 1)
+                # TF stores beta^(t+1).  beta1_power = 0.9^(t+1) underflows fp32 after ~830 steps (denormal, then 0), so
+                # the step count is read from beta2_power = 0.999^(t+1) (good for ~87 000 steps); when that is gone too
+                # the bias corrections are 1 to fp32 precision anyway and a large count stands in.
+                t_new = None
+                for name, beta in (("optimizer/beta2_power", 0.999), ("beta2_power", 0.999),
+                                   ("optimizer/beta1_power", 0.9), ("beta1_power", 0.9)):
+                    if name in state:
+                        v = float(state[name])
+                        if 1e-30 < v < 1.0:
+                            t_new = round(np.log(v) / np.log(beta)) - 1
+                            break
+                        if v <= 1e-30:
+                            t_new = 1000000
+                if t_new is not None:
+                    self.t.fill_(max(0, t_new))
 
     def step(self):
         """One update of every parameter with multi-tensor (``torch._foreach_*``) ops: a handful of launches

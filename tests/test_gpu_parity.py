@@ -72,11 +72,27 @@ def test_ragged_window_counts_random_weights(n_windows):
     assert err < TOL, err
 
 
-@pytest.mark.parametrize("n_windows", [1024, 1040, 4096, 4112])
-def test_launch_regime_boundaries(n_windows):
-    """One pass each side of the two regime switches of the fp32 path: hoisted x projection up to CUs/4 tiles
-    (1024 windows), latency-mode kernels up to CUs tiles (4096 windows), one wave per tile beyond."""
+def _regime_sizes():
+    """Window counts either side of every launch-regime switch of the fp32 path, read from the library
+    (cf_launch_regimes) instead of hard-coded: hoisted x projection up to 3*CUs/16 tiles (768 windows on 256 CUs),
+    cooperative latency-mode kernels up to CUs tiles (4096 windows), one wave per tile beyond."""
     from catfish_amd.engine import HipEngine
+    eng = HipEngine(oracle.random_weights(seed=5), device=0, max_windows_per_pass=8192)
+    try:
+        return eng.launch_regimes()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("which", ["hoist_max", "hoist_max+16", "coop_max", "coop_max+16", "coop_max+3"])
+def test_launch_regime_boundaries(which):
+    """One pass each side of the two regime switches of the fp32 path, plus a ragged last tile in throughput mode
+    (coop_max + 3 windows), against the fp64 oracle at the 1e-4 gate and the fp32 oracle at 2e-5."""
+    from catfish_amd.engine import HipEngine
+    reg = _regime_sizes()
+    assert reg["hoist_max"] == 16 * (3 * reg["n_cu"] // 16) and reg["coop_max"] == 16 * reg["n_cu"]
+    name, _, extra = which.partition("+")
+    n_windows = reg[name] + int(extra or 0)
     w = oracle.random_weights(seed=5)
     rng = np.random.default_rng(n_windows)
     x = rng.normal(0, 1.5, size=(n_windows, 35)).astype(np.float32)
@@ -85,8 +101,29 @@ def test_launch_regime_boundaries(n_windows):
         got = eng.infer_host(x)
     finally:
         eng.close()
-    want = oracle.forward(x, w, np.float32)
-    assert np.abs(got - want).max() < 2e-5
+    assert np.abs(got - oracle.forward(x, w, np.float64)).max() < TOL
+    assert np.abs(got - oracle.forward(x, w, np.float32)).max() < 2e-5
+
+
+@pytest.mark.parametrize("n_windows", [30208 - 7, 30208, 30208 + 7])
+def test_throughput_kernel_at_benchmark_size(ckpt_weights, n_windows):
+    """The headline kernel (one wave per tile, 3.7 rounds on 256 CUs) at BASELINE configs[1]'s launch size and with
+    ragged last tiles either side of it: the last 48 windows (the ragged tile and its neighbours) plus 80 random
+    ones against the fp64 oracle; all windows bit-identical to the same windows inferred in a small call."""
+    from catfish_amd.engine import HipEngine
+    rng = np.random.default_rng(n_windows)
+    x = rng.normal(0, 1.5, size=(n_windows, 35)).astype(np.float32)
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=32768)
+    try:
+        got = eng.infer_host(x).reshape(n_windows, 35)
+        idx = np.concatenate([np.arange(n_windows - 48, n_windows), rng.integers(0, n_windows - 48, size=80)])
+        small = eng.infer_host(x[idx]).reshape(len(idx), 35)        # 128 windows: latency-mode kernels
+    finally:
+        eng.close()
+    want = oracle.forward(x[idx], ckpt_weights, np.float64).reshape(len(idx), 35)
+    assert np.abs(got[idx] - want).max() < TOL
+    assert np.array_equal(got[idx], small)                          # every regime gives the same bits
+    assert np.isfinite(got).all()
 
 
 def test_device_path_matches_host_path(engine, golden_read):
@@ -157,6 +194,48 @@ def test_fused_single_launch_matches_per_layer_launches(ckpt_weights, n_windows)
         a.close(); b.close()
 
 
+@pytest.mark.timeout(900)
+def test_fused_auto_regime_is_bit_identical_and_error_free(ckpt_weights):
+    """The regime the CLI ships for big jobs (cli.py: 131 072-window launches, fuse_layers = auto): 768+ eight-tile
+    groups per layer on 256 CUs, i.e. three layer pools of workgroups that cannot all be resident, layer l+1 waiting
+    on agent-scope flags.  fuse_layers=None (auto) and =True must equal fuse_layers=False bit for bit, either side of
+    the auto threshold (read from cf_launch_regimes) and at 131 072 windows with a ragged tail, repeated; the sticky
+    device error flag must stay clear; a sample including the ragged tile is checked against the fp64 oracle."""
+    from catfish_amd.engine import HipEngine
+    cap = 131072
+    per_layer = HipEngine(ckpt_weights, device=0, max_windows_per_pass=cap, fuse_layers=False)
+    auto = HipEngine(ckpt_weights, device=0, max_windows_per_pass=cap, fuse_layers=None)
+    forced = HipEngine(ckpt_weights, device=0, max_windows_per_pass=cap, fuse_layers=True)
+    try:
+        fmin = auto.launch_regimes()["fuse_auto_min"]
+        assert fmin == (8 * 6 * (auto.launch_regimes()["n_cu"] // 2) - 8) * 16 + 1          # 98 177 windows on 256 CUs
+        assert per_layer.launch_regimes()["fuse_auto_min"] == 0 and forced.launch_regimes()["fuse_auto_min"] == 1
+        rng = np.random.default_rng(42)
+        x_all = rng.normal(0, 1.5, size=(cap, 35)).astype(np.float32)
+        for n in (fmin - 1, fmin, fmin + 127, cap - 5, cap):
+            x = x_all[:n]
+            ref = per_layer.infer_host(x)
+            for rep in range(2):
+                auto.profile_enable(True)
+                auto.profile_reset()
+                got = auto.infer_host(x)
+                slots = auto.profile_read()
+                auto.profile_enable(False)
+                assert ("gru_fused" in slots) == (n >= fmin), (n, sorted(slots))      # the regime under test really ran
+                assert np.array_equal(got, ref), (n, rep)
+                auto.check_error()
+            assert np.array_equal(forced.infer_host(x), ref), n
+            forced.check_error()
+        # oracle spot check of the fused result at the largest ragged size
+        n = cap - 5
+        got = auto.infer_host(x_all[:n]).reshape(n, 35)
+        idx = np.concatenate([np.arange(n - 40, n), rng.integers(0, n - 40, size=56)])
+        want = oracle.forward(x_all[idx], ckpt_weights, np.float64).reshape(len(idx), 35)
+        assert np.abs(got[idx] - want).max() < TOL
+    finally:
+        per_layer.close(); auto.close(); forced.close()
+
+
 def test_internal_streams_option_is_bit_identical(ckpt_weights):
     """cf_hparams.n_streams > 1 (sub-batches of one call on internal streams) gives the same bits."""
     from catfish_amd.engine import HipEngine
@@ -182,7 +261,7 @@ def test_other_depths(n_layers, n_layers_res, precision):
         pytest.skip("plain RNN type is fp32 only")
     w = oracle.random_weights(seed=7 * n_layers + n_layers_res, n_layers=n_layers, n_layers_res=n_layers_res)
     rng = np.random.default_rng(3)
-    for n in (50, 3000):                       # cooperative small-call kernels and the throughput kernels
+    for n in (50, 3000, 4200):                 # latency mode with hoisted x projection, cooperative kernels, throughput kernels (> CUs tiles)
         x = rng.normal(0, 1.3, size=(n, 35)).astype(np.float32)
         eng = HipEngine(w, n_layers=n_layers, n_layers_res=n_layers_res, device=0, max_windows_per_pass=4096,
                         precision=precision)

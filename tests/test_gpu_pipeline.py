@@ -108,6 +108,40 @@ def test_packed_variable_length_reads_match_per_read_oracle(model, ckpt_weights)
         assert g == (w_spans, w_len)
 
 
+def test_config4_bf16_packed_varlen(ckpt_weights):
+    """BASELINE configs[3] as stated: variable-length reads 512..16384 (log-uniform, seed 2) as raw DAC squiggles, in
+    length-bucketed PACKED launches, bf16 biGRU arithmetic -- through batching.infer_reads_dac (device normalisation,
+    forward pass, device post-processing).  Judged like SURVEY 8d says: label match rate against the fp32 oracle
+    (>= 0.998 over all samples) and max |dp| <= 1e-2 per read; edge lengths 512, 16384, 35k and 35k + 1 included."""
+    from catfish_amd import batching
+    from catfish_amd.engine import HipEngine
+    rng = np.random.default_rng(2)
+    lens = np.exp(rng.uniform(np.log(512), np.log(16384), size=22)).astype(int).tolist() + [512, 16384, 35 * 40, 35 * 40 + 1, 35 * 300]
+    dacs = [oracle.synthetic_dac(1, n, seed=2000 + i)[0] for i, n in enumerate(lens)]
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=2048, precision="bf16")
+    try:
+        res, probs = batching.infer_reads_dac(eng, dacs, max_windows=2048, return_probs=True)   # several buckets
+        # the fp32 engine on the same packed batches: spans of the two precisions must agree almost everywhere
+    finally:
+        eng.close()
+    n_match = n_tot = 0
+    worst = 0.0
+    for d, (spans, n), p in zip(dacs, res, probs):
+        assert n == len(d) and p.shape == (n,)
+        x, pad = oracle.pad_and_window(oracle.normalize_raw_signal(d))
+        want = oracle.forward(x, ckpt_weights, np.float32)[:n]
+        worst = max(worst, float(np.abs(p - want).max()))
+        m = (p >= 0.5) == (want >= 0.5)
+        n_match += int(m.sum()); n_tot += n
+        assert m.mean() >= 0.99, (n, m.mean())
+        # spans are what the tool emits: they come from the bf16 labels through correct_short + hp_in_pred
+        lab = oracle.correct_short(oracle.class_from_threshold(p))
+        assert spans == (oracle.hp_in_pred(lab) if lab.any() else [])
+    print("config 4: label match %.5f over %d samples, max |dp| %.2e" % (n_match / n_tot, n_tot, worst))
+    assert n_match / n_tot >= 0.998
+    assert worst <= 1e-2
+
+
 def test_full_size_properties(model):
     """BASELINE size (256 reads x 118 windows): window-permutation equivariance, batch-split
     invariance and run-to-run determinism -- size-independent properties of independent windows."""
@@ -199,6 +233,49 @@ def test_train_network_then_infer_uses_updated_weights(hp):
     m.engine.close()
 
 
+def test_train_save_load_infer_loop(hp, tmp_path, monkeypatch):
+    """The loop the reference's training script closes (networks/train_validate.py:323-334,154 ->
+    neural_network.load_network, neural_network.py:26-34): build with save=True (model directory + report),
+    train 20 steps on balanced synthetic batches, checkpoint, validate on NPZ reads, then load the directory back
+    with load_network and get the same predictions as the trained model (and as the oracle on the saved weights)."""
+    pytest.importorskip("torch")
+    from catfish_amd import neural_network, train_validate as tv, checkpoint
+    monkeypatch.chdir(tmp_path)
+    net = tv.build_model("ResNetRNN", save=True, **dict(hp, batch_size=64, train_seed=0))
+    net.initialize_network(seed=4)
+    db = tv.synthetic_example_db(n_reads=2, read_len=12000, seed=2)
+    val_dir = tmp_path / "val"
+    val_dir.mkdir()
+    squiggles = []
+    for i in range(3):
+        raw, lab = tv.synthetic_labelled_read(3000 + 35 * i, seed=50 + i)
+        np.savez(val_dir / ("sq%d.npz" % i), raw=raw, base_labels=lab)
+        squiggles.append(str(val_dir / ("sq%d.npz" % i)))
+    acc = tv.train_and_validate(net, db, 20 * 64, squiggles, 2000, net.model_path, 0, 856)
+    assert 0.0 <= acc <= 1.0 and np.isfinite(net.train_loss)
+    report = open(net.model_path + ".txt").read()
+    assert "Training on 1280 examples in 20 batches" in report and "Saved checkpoint at step 20" in report
+    val_report = open(os.path.basename(net.model_path) + ".txt").read()       # validate() writes <basename>.txt in the CWD
+    assert "---NEXT ROUND OF VALIDATION---" in val_report and "F1 score" in val_report
+    assert (net.tp, net.fp, net.tn, net.fn) == (0, 0, 0, 0)                    # counters reset after validation
+    # load the model directory back like the inference tool does
+    loaded = neural_network.load_network("ResNetRNN", net.model_path, checkpoint=20)
+    x = np.random.default_rng(0).normal(0, 1.2, size=(40, 35, 1))
+    got = loaded.infer(x)
+    assert np.array_equal(got, net.infer(x))
+    saved = checkpoint.read_inference_weights(os.path.join(net.model_path, "checkpoints"), "ckpnt-20")
+    assert np.abs(got - oracle.forward(x, saved, np.float64)).max() < 1e-4
+    assert loaded.optimizer_state and any(k.endswith("/RMSProp") for k in loaded.optimizer_state)
+    # evaluate(): accuracy / logits-based loss of a batch against the oracle's logits
+    y = (np.arange(40 * 35).reshape(40, 35, 1) % 3 == 0).astype(np.float64)
+    acc2, loss2 = loaded.evaluate(x, y)
+    _, st = oracle.forward(x, saved, np.float64, return_stages=True)
+    z = st["logits"].reshape(-1)
+    want_loss = np.mean(np.maximum(z, 0) - z * y.reshape(-1) + np.log1p(np.exp(-np.abs(z))))
+    assert abs(loss2 - want_loss) < 1e-4 and abs(acc2 - np.mean((z >= 0) == (y.reshape(-1) == 1))) < 1e-3
+    loaded.engine.close(); net.engine.close()
+
+
 def test_plain_rnn_type_matches_oracle(hp):
     """build_model("RNN") (neural_network.py:17-18): 3 x biGRU directly on the raw window, no residual blocks."""
     from catfish_amd import neural_network
@@ -248,7 +325,12 @@ def test_streaming_pipeline_matches_oracle(model, ckpt_weights):
     flat = [[int(a), int(b)] for a, b in zip(s, e)]
     assert flat == [sp for spans, _ in got[:3] for sp in spans] and list(ln) == lens[:3]
     with pytest.raises(ValueError):
-        pipe.submit([np.zeros(20000, np.int16)])
+        pipe.submit([np.zeros(7000, np.int16), np.zeros(7000, np.int16)])     # several reads beyond the batch size
+    # ONE read longer than the batch size grows the staging buffers instead (a directory may hold such a read)
+    long_dac = oracle.synthetic_dac(1, 20000, seed=77)[0]
+    (spans, n), = pipe.collect(pipe.submit([long_dac]))
+    w_spans, w_len, _ = oracle.infer_read(oracle.normalize_raw_signal(long_dac), ckpt_weights, np.float32)
+    assert (spans, n) == (w_spans, w_len)
 
 
 @pytest.mark.parametrize("n", [40, 2100])
