@@ -11,7 +11,11 @@ the reference's bundled checkpoint ckpnt-30000.  A step = device-resident normal
 -> device-resident per-sample probabilities through the C ABI (cf_infer).  Reads shard across
 ranks with no collective on the data path (weak scaling: every rank runs K steps of its own reads).
 
-``value`` counts UN-PADDED signal samples (256 x 4096 per step and rank).
+``value`` counts UN-PADDED signal samples (256 x 4096 per step and rank).  The line also carries
+informational objects that are never the value: ``other_precisions`` (bf16x3 / bf16 on the same
+workload, each with its own roofline), ``config4`` (BASELINE configs[3]: variable-length reads, packed,
+bf16), ``host_to_host_pipeline`` (PCIe-inclusive) and ``sharded_gather`` (BASELINE configs[2]'s path:
+reads sharded over the ranks, per-rank streaming pipeline, gloo host gather on rank 0).
 """
 from __future__ import annotations
 
@@ -33,21 +37,29 @@ FLOP_PER_SAMPLE = 389504            # SURVEY.md 8d / BASELINE.md 2 (2 x 194 752 
 FLOP_PER_SAMPLE_GRU128 = 2 * 2 * (128 + 64) * 192   # one CIN=128 biGRU layer: 2 dirs x 2 FLOP x 192x192 MAC
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
+SHARDED_READS_PER_RANK = 12500      # BASELINE configs[2]: 100 000 reads over 8 GPUs
+CONFIG4_READS = 2048                # BASELINE configs[3] names 10 000 reads; the informational leg times a 2048-read sample
+
+
+def squiggle_dac(rng, length):
+    """One seeded synthetic read: int16 DAC squiggle of SURVEY 8d (levels N(500,60^2), dwell Geometric(1/9),
+    noise N(0,8^2), clipped to [0,2047])."""
+    n_ev = length // 4 + 8
+    dwell = rng.geometric(1.0 / 9.0, size=n_ev)
+    while dwell.sum() < length:
+        dwell = np.concatenate([dwell, rng.geometric(1.0 / 9.0, size=n_ev)])
+    levels = rng.normal(500.0, 60.0, size=len(dwell))
+    sig = np.repeat(levels, dwell)[:length] + rng.normal(0.0, 8.0, size=length)
+    return np.clip(np.rint(sig), 0, 2047).astype(np.int16)
 
 
 def make_reads(n_reads, seed, return_dac=False):
     """Seeded synthetic reads -> normalised float32 windows [n_reads, 118, 35]."""
     rng = np.random.default_rng(seed)
-    n_ev = READ_LEN // 4 + 8
     out = np.zeros((n_reads, 118 * WINDOW), dtype=np.float32)
     dacs = np.zeros((n_reads, READ_LEN), dtype=np.int16)
     for i in range(n_reads):
-        dwell = rng.geometric(1.0 / 9.0, size=n_ev)
-        while dwell.sum() < READ_LEN:
-            dwell = np.concatenate([dwell, rng.geometric(1.0 / 9.0, size=n_ev)])
-        levels = rng.normal(500.0, 60.0, size=len(dwell))
-        sig = np.repeat(levels, dwell)[:READ_LEN] + rng.normal(0.0, 8.0, size=READ_LEN)
-        dac = np.clip(np.rint(sig), 0, 2047).astype(np.int16)
+        dac = squiggle_dac(rng, READ_LEN)
         shift = np.median(dac)                       # infer.py:100-105
         scale = np.median(np.abs(dac - shift))
         out[i, :READ_LEN] = ((dac - shift) / scale).astype(np.float32)
@@ -63,9 +75,176 @@ def load_weights():
 
 def cpu_baseline():
     """CPU oracle timed on the host cores (oracle/cpu_baseline.py); runs BEFORE the GPU is initialised
-    because it spawns worker processes."""
+    because it spawns worker processes.  Two figures: the 1-GPU box's CPU share (16 workers) as ``value`` and
+    every core this process may run on as ``all_cores``."""
     from oracle import cpu_baseline as cb
-    return cb.run(os.path.join(ROOT, "tests", "golden", "ckpnt-30000-inference.npz"), read_len=READ_LEN)
+    wpath = os.path.join(ROOT, "tests", "golden", "ckpnt-30000-inference.npz")
+    res = cb.run(wpath, read_len=READ_LEN, budget_s=8.0, workers=16)
+    n_aff = cb.affinity_cores()
+    if n_aff > res["cores"]:
+        full = cb.run(wpath, read_len=READ_LEN, budget_s=6.0, workers=min(n_aff, 256))
+        res["all_cores"] = {"value": full["value"], "unit": full["unit"], "cores": full["cores"], "sample": full["sample"]}
+    return res
+
+
+def traffic_record():
+    """HBM bytes per launch of the dominant kernel from the last FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json,
+    written by tools/collect_traffic.sh): a STORED measurement -- PMC counters cannot be read from inside this
+    process -- so the line says which commit and command it came from."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as fh:
+        t = json.load(fh)
+    src = {"file": "profiles/traffic.json", "kind": "stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run",
+           "commit": t.get("commit"), "collected": t.get("collected"), "kernel_avg_ms_at_collection": t.get("kernel_avg_ms")}
+    return t, src
+
+
+def mid_roofline(kern, precision, samples_per_launch, traffic=None, traffic_source=None):
+    if "gru_layer_mid" not in kern:
+        return None
+    ms, n = kern["gru_layer_mid"]
+    achieved = FLOP_PER_SAMPLE_GRU128 * samples_per_launch / (ms / n * 1e-3) / 1e12
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    kname = "gru_layer_kernel<128,false>" if precision == "fp32" else \
+        "gru_layer_bf16_kernel<128,false,%d>" % (2 if precision == "bf16x3" else 1)
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": ms / n,
+            "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_launch}
+
+
+def timed_steps(eng, batches, outs, n, torch):
+    t0 = time.perf_counter()
+    for i in range(n):
+        eng.infer_device(batches[i % len(batches)], out=outs[i & 1])
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def warm_by_time(eng, batches, outs, seconds, torch):
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < seconds:
+        for i in range(4):
+            eng.infer_device(batches[i % len(batches)], out=outs[i & 1])
+        torch.cuda.synchronize()
+
+
+def leg_config4(weights, local_rank, torch):
+    """BASELINE configs[3]: variable-length reads 512..16384 (log-uniform, seed 2), DAC squiggles normalised on the
+    device, packed into length-bucketed launches, bf16.  Timed: device-resident packed windows -> probabilities ->
+    device labels (cf_infer + cf_postprocess)."""
+    from catfish_amd import batching
+    from catfish_amd.engine import HipEngine
+    from catfish_amd.infer import padding_size_for
+    from oracle import catfish_oracle as oracle
+    rng = np.random.default_rng(2)
+    lens = np.rint(np.exp(rng.uniform(np.log(512), np.log(16384), size=CONFIG4_READS))).astype(np.int64)
+    dacs = [squiggle_dac(rng, int(n)) for n in lens]
+    max_windows = READS_PER_STEP * 118
+    eng = HipEngine(weights, device=local_rank, max_windows_per_pass=max_windows, precision="bf16")
+    dev = torch.device("cuda", local_rank)
+    packed = []
+    for b in batching.length_buckets(lens, max_windows):
+        ln = lens[b]
+        dac_off = np.concatenate(([0], np.cumsum(ln)))
+        n_win = np.array([(int(n) + padding_size_for(int(n))) // WINDOW for n in ln], dtype=np.int64)
+        win_off = np.concatenate(([0], np.cumsum(n_win)))
+        x = torch.empty(int(win_off[-1]), WINDOW, dtype=torch.float32, device=dev)
+        eng.normalize_device(torch.from_numpy(np.concatenate([dacs[i] for i in b])).to(dev),
+                             torch.from_numpy(dac_off).to(dev), torch.from_numpy(win_off).to(dev), out=x)
+        packed.append((x, torch.from_numpy(win_off * WINDOW).to(dev), torch.from_numpy(ln).to(dev), int(ln.sum())))
+    torch.cuda.synchronize()
+
+    def run_all():
+        for x, offs, ln, _ in packed:
+            eng.postprocess_device(eng.infer_device(x), offs, ln)
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < 0.4:
+        run_all()
+        torch.cuda.synchronize()
+    eng.profile_enable(True, every=1)
+    eng.profile_reset()
+    rep = 3
+    t0 = time.perf_counter()
+    for _ in range(rep):
+        run_all()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / rep
+    kern = eng.profile_read()
+    eng.profile_enable(False)
+    # parity on four reads (shortest, longest, two others) against the fp32 oracle, as SURVEY 8d asks for this config
+    idx = [int(np.argmin(lens)), int(np.argmax(lens)), 0, 1]
+    _, probs = batching.infer_reads_dac(eng, [dacs[i] for i in idx], max_windows=max_windows, return_probs=True)
+    n_match = n_tot = 0
+    maxdp = 0.0
+    for p, i in zip(probs, idx):
+        xw, _pad = oracle.pad_and_window(oracle.normalize_raw_signal(dacs[i]))
+        want = oracle.forward(xw, weights, np.float32)[:len(p)]
+        n_match += int(((p >= 0.5) == (want >= 0.5)).sum())
+        n_tot += len(p)
+        maxdp = max(maxdp, float(np.abs(p - want).max()))
+    eng.close()
+    total = int(lens.sum())
+    windows = sum(int(p[0].shape[0]) for p in packed)
+    value = total / dt
+    roof = None
+    if "gru_layer_mid" in kern:
+        ms, n = kern["gru_layer_mid"]
+        # the CIN = 128 mid layer over ALL buckets of one repetition: algorithmic flops of the un-padded samples
+        mid_s = ms / rep * 1e-3
+        ach = FLOP_PER_SAMPLE_GRU128 * total / mid_s / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                "traffic": None, "kernel": "gru_layer_bf16_kernel<128,false,1>", "launches_per_repetition": n // rep,
+                "ms_per_repetition": ms / rep}
+    return {"workload": "configs[3]: %d reads, lengths LogUniform[512,16384] (seed 2), DAC squiggles, length-bucketed packed "
+                        "launches of <= %d windows, bf16 biGRU arithmetic, device-resident" % (CONFIG4_READS, max_windows),
+            "value": value, "unit": "samples/s", "dtype": "bf16 (f32 accumulate)", "reads": CONFIG4_READS, "buckets": len(packed),
+            "total_samples": total, "padding_overhead": windows * WINDOW / total - 1.0, "ms_per_pass": dt * 1e3,
+            "whole_pass_frac_of_bf16_peak": value * FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+            "roofline": roof, "kernels_ms_per_pass": {k: v[0] / rep for k, v in kern.items()},
+            "label_match_vs_fp32_oracle": n_match / n_tot, "max_abs_dp_vs_fp32_oracle": maxdp, "parity_sample": "%d samples of 4 reads" % n_tot}
+
+
+def leg_sharded_gather(eng, weights, rank, world, dist, torch):
+    """BASELINE configs[2]'s path, timed from the first submit to the gathered result on rank 0: reads (seed 1) sharded
+    over the ranks by ``catfish_amd.sharding`` (LPT by windows), each rank streams ITS reads through its engine's
+    ReadPipeline (int16 DAC up, normalise + forward + post-processing on device, run lists down), per-read
+    ``(spans, length)`` gathered on rank 0 over a gloo group.  Weak scaling: 12 500 reads per rank (= 100 000 on 8)."""
+    from catfish_amd import sharding
+    n_total = SHARDED_READS_PER_RANK * world
+    lengths = [READ_LEN] * n_total
+    mine = sharding.shard_reads(lengths, world)[rank]
+    reads = [None] * n_total
+    for i in mine:                                        # every rank generates only its own shard
+        reads[i] = squiggle_dac(np.random.default_rng([1, i]), READ_LEN)
+    group = sharding.host_gather_group() if world > 1 else None
+    batch = READS_PER_STEP * READ_LEN
+    runner = sharding.EngineBatchRunner(eng, batch)
+    # warm the pipeline (pinned buffers, first launches) outside the timed region
+    list(runner.run([[reads[i] for i in mine[:READS_PER_STEP]]]))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = sharding.infer_reads_sharded(eng, reads, lengths=lengths, max_samples_per_batch=batch, batch_runner=runner,
+                                       rank=rank, world_size=world, gather_group=group)
+    dt = time.perf_counter() - t0                          # rank 0: includes the gather of every rank's results
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        return None
+    from oracle import catfish_oracle as oracle
+    ok = all(r is not None and r[1] == READ_LEN for r in res)
+    for i in mine[:2]:                                     # untimed check of two reads against the oracle
+        spans, n, _ = oracle.infer_read(oracle.normalize_raw_signal(reads[i]), weights, np.float32)
+        ok = ok and res[i] == (spans, n)
+    return {"workload": "configs[2]: %d reads x %d samples (seed 1) sharded over %d rank(s), %d per rank; host gather on rank 0"
+                        % (n_total, READ_LEN, world, SHARDED_READS_PER_RANK),
+            "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "reads": n_total, "n_gpus": world,
+            "results_ok": bool(ok), "spans_found": int(sum(len(r[0]) for r in res)),
+            "what": "pinned int16 DAC -> per-rank ReadPipeline (cf_normalize, cf_infer, cf_postprocess, cf_spans) -> per-read "
+                    "span lists -> gloo gather_object on rank 0; PCIe, host span assembly and the gather included; never the headline value"}
 
 
 def main():
@@ -78,7 +257,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
                     help="arithmetic of the biGRU matmuls (fp32 = exact fp32 MFMA, the BASELINE configs[1] dtype)")
     ap.add_argument("--no-extra-precisions", action="store_true",
-                    help="skip the short informational legs that time the other precisions")
+                    help="skip the informational legs (other precisions, config 4, host-to-host pipeline)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="skip the informational sharded_gather leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="run untimed steps for this long before the W warm-up steps: the GPU clocks down while the CPU "
@@ -137,11 +317,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    tw = time.perf_counter()
-    while (time.perf_counter() - tw) * 1e3 < args.prewarm_ms:          # clock warm-up, outside the W + K steps
-        for i in range(4):
-            eng.infer_device(batches[i % n_batches], out=outs[i & 1])
-        torch.cuda.synchronize()
+    warm_by_time(eng, batches, outs, args.prewarm_ms * 1e-3, torch)      # clock warm-up, outside the W + K steps
     for i in range(args.warmup):
         eng.infer_device(batches[i % n_batches], out=outs[i & 1])
     torch.cuda.synchronize()
@@ -159,6 +335,7 @@ def main():
     dt = time.perf_counter() - t0
     kern = eng.profile_read() if not args.no_kernel_events else {}
     eng.profile_enable(False)
+    eng.check_error()
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -169,8 +346,9 @@ def main():
     value = world * args.steps * samples_per_step / dt
 
     result = None
+    parity_ok = True
     if rank == 0:
-        # parity spot-check of the benchmarked configuration against the oracle (not timed)
+        # parity gate of the benchmarked configuration against the oracle (not timed): a build that fails it reports no value
         from oracle import catfish_oracle as oracle
         chk = reads[:2]     # the launch keeps the benchmark's size (rocprof averages stay comparable)
         got = eng.infer_device(batches[0], out=outs[0]).cpu().numpy()[:2 * 118 * WINDOW].astype(np.float64)
@@ -178,69 +356,65 @@ def main():
         want32 = oracle.forward(chk.reshape(-1, WINDOW), weights, np.float32)
         max_dp = float(np.abs(got - want64).max())
         match = float(np.mean((got >= 0.5) == (want32 >= 0.5)))
+        gate = {"fp32": 1e-4, "bf16x3": 1e-4, "bf16": 3e-2}[args.precision]
+        min_match = 1.0 if args.precision != "bf16" else 0.998
+        parity_ok = bool(np.isfinite(got).all() and max_dp < gate and match >= min_match)
 
-        roof = None
-        if "gru_layer_mid" in kern:
-            ms, n = kern["gru_layer_mid"]
-            avg_s = ms / n * 1e-3
-            achieved = FLOP_PER_SAMPLE_GRU128 * samples_per_step / avg_s / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("gru_layer_mid_bytes_per_launch")
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-            kname = "gru_layer_kernel<128,false>" if args.precision == "fp32" else \
-                "gru_layer_bf16_kernel<128,false,%d>" % (2 if args.precision == "bf16x3" else 1)
-            if args.precision != "fp32":
-                traffic = None      # profiles/traffic.json was collected for the fp32 kernel
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak, "traffic": traffic,
-                    "kernel": kname, "avg_launch_ms": ms / n,
-                    "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_step}
+        traffic, traffic_src = (None, None)
+        if args.precision == "fp32":
+            t, traffic_src = traffic_record()
+            traffic = t.get("gru_layer_mid_bytes_per_launch") if t else None
+        roof = mid_roofline(kern, args.precision, samples_per_step, traffic, traffic_src)
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         result = {
             "metric": "signal samples/s classified",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value if parity_ok else None, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "prewarm_ms": args.prewarm_ms, "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-operand fp32 emulation, f32 accumulate)",
-                                           "bf16": "bf16 (f32 accumulate)"}[args.precision], "data": "synthetic",
+            "prewarm_ms": args.prewarm_ms, "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-operand fp32 emulation, f32 accumulate)",
+                      "bf16": "bf16 (f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 4096-sample reads, 256 reads (30208 windows of 35) "
                                    "per step and GPU, fp32, ckpnt-30000 weights",
                        "reads_per_step": READS_PER_STEP, "read_len": READ_LEN, "windows_per_step": READS_PER_STEP * 118,
                        "parallelism": "reads sharded over %d GPU(s), no collective" % world},
             "roofline": roof,
             "whole_pass": {"achieved_tflops": value / world * FLOP_PER_SAMPLE / 1e12,
-                           "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 /
-                           (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS)},
+                           "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 / peak},
             "kernels_ms": {k: v[0] / v[1] for k, v in kern.items()},
-            "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match, "gate": 1e-4},
+            "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match, "gate": gate,
+                       "min_label_match": min_match, "passed": parity_ok},
         }
+        if not parity_ok:
+            result["unverified_value"] = value
         result["cpu_baseline"] = cpu_res
     # informational legs: the same workload with the other GRU arithmetics (not the headline value)
     if world == 1 and not args.no_extra_precisions:
+        from oracle import catfish_oracle as oracle
         extra = {}
         for prec in ("fp32", "bf16x3", "bf16"):
             if prec == args.precision:
                 continue
             e2 = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, precision=prec)
-            tw = time.perf_counter()                 # warm up by time: the GPU clocks down while the CPU oracle ran
-            while time.perf_counter() - tw < 0.5:
-                for i in range(4):
-                    e2.infer_device(batches[i % n_batches], out=outs[i & 1])
-                torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            warm_by_time(e2, batches, outs, 0.5, torch)      # the GPU clocks down while the CPU oracle ran
             n2 = max(5, args.steps // 2)
-            for i in range(n2):
-                e2.infer_device(batches[i % n_batches], out=outs[i & 1])
-            torch.cuda.synchronize()
-            d2 = time.perf_counter() - t1
-            from oracle import catfish_oracle as oracle
+            e2.profile_enable(True, every=2)
+            e2.profile_reset()
+            d2 = timed_steps(e2, batches, outs, n2, torch)
+            k2 = e2.profile_read()
+            e2.profile_enable(False)
             got = e2.infer_device(batches[0], out=outs[0]).cpu().numpy()[:118 * WINDOW].astype(np.float64)
             want = oracle.forward(reads[0], weights, np.float64)
-            extra[prec] = {"value": n2 * samples_per_step / d2, "unit": "samples/s", "ms_per_step": d2 / n2 * 1e3,
-                           "max_abs_dp_vs_fp64_oracle": float(np.abs(got - want).max())}
+            v2 = n2 * samples_per_step / d2
+            extra[prec] = {"value": v2, "unit": "samples/s", "ms_per_step": d2 / n2 * 1e3,
+                           "max_abs_dp_vs_fp64_oracle": float(np.abs(got - want).max()),
+                           "label_match_vs_fp64_oracle": float(np.mean((got >= 0.5) == (want >= 0.5))),
+                           "roofline": mid_roofline(k2, prec, samples_per_step),
+                           "whole_pass_frac_of_mfma_peak": v2 * FLOP_PER_SAMPLE / 1e12 /
+                           (PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS),
+                           "kernels_ms": {k: v[0] / v[1] for k, v in k2.items()}}
             e2.close()
         result["other_precisions"] = extra
+        result["config4"] = leg_config4(weights, local_rank, torch)
         # informational: host-to-host rate of the streaming pipeline (pinned int16 DAC in, spans out, PCIe inclusive)
         from catfish_amd.pipeline import ReadPipeline
         _, dacs = make_reads(READS_PER_STEP, seed=77, return_dac=True)
@@ -257,12 +431,24 @@ def main():
                                            "ms_per_batch": d3 / len(pb) * 1e3,
                                            "what": "pinned int16 DAC -> cf_normalize -> cf_infer -> cf_postprocess -> cf_spans -> "
                                                    "host span table, double-buffered; never the headline value"}
+    if not args.no_sharded_leg and args.precision == "fp32":
+        try:
+            sg = leg_sharded_gather(eng, weights, rank, world, dist, torch)
+        except Exception as exc:      # informational leg: never lose the headline line to it
+            sg = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if world > 1:
+                sys.stderr.write("bench.py: sharded_gather leg failed on rank %d: %s\n" % (rank, exc))
+        if rank == 0:
+            result["sharded_gather"] = sg
     eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+        if not parity_ok:
+            sys.stderr.write("bench.py: PARITY GATE FAILED (max |dp| %.3g, label match %.5f): no value reported\n" % (max_dp, match))
+            sys.exit(3)
 
 
 if __name__ == "__main__":

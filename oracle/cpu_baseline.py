@@ -36,15 +36,22 @@ def _worker(args):
     return n, time.perf_counter() - t0
 
 
-def run(weights_path, read_len=4096, budget_s=12.0, workers=None):
-    """-> dict for bench.py's "cpu_baseline" object."""
-    import multiprocessing as mp
+def affinity_cores():
+    """Cores this process may run on (the GPU box reports 256)."""
     ncpu = os.cpu_count() or 1
     try:
         ncpu = min(ncpu, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    workers = workers or max(1, min(16, ncpu))   # a 1-GPU box's CPU share is 16 cores
+    return ncpu
+
+
+def run(weights_path, read_len=4096, budget_s=12.0, workers=None):
+    """-> dict for bench.py's "cpu_baseline" object.  ``workers``: single-threaded worker processes (default 16 = a
+    1-GPU box's CPU share), never more than the affinity mask allows."""
+    import multiprocessing as mp
+    ncpu = affinity_cores()
+    workers = max(1, min(workers or 16, ncpu))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(workers) as pool:
