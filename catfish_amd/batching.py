@@ -97,13 +97,18 @@ def spans_from_labels(labels, sample_offsets, n_reads, ext_left=EXT_LEFT, ext_ri
 
 
 def spans_from_runs(starts, ends, sample_offsets, n_reads, ext_left=EXT_LEFT, ext_right=EXT_RIGHT):
-    """Sorted packed run boundaries (engine.spans_device) -> per-read [start - 11, end + 16] lists."""
+    """Sorted packed run boundaries (engine.spans_device) -> per-read [start - 11, end + 16] lists.
+
+    Vectorised: one ``tolist`` of the whole span table, then one slice per read (runs are sorted, so a read's
+    spans are contiguous)."""
+    starts = np.asarray(starts, dtype=np.int64)
+    ends = np.asarray(ends, dtype=np.int64)
+    sample_offsets = np.asarray(sample_offsets, dtype=np.int64)
     read_of = np.searchsorted(sample_offsets, starts, side="right") - 1
     base = sample_offsets[read_of]
-    out = [[] for _ in range(n_reads)]
-    for r, s, e in zip(read_of.tolist(), (starts - base).tolist(), (ends - base).tolist()):
-        out[r].append([s - ext_left, e + ext_right])
-    return out
+    pairs = np.stack([starts - base - ext_left, ends - base + ext_right], axis=1).tolist()
+    bounds = np.concatenate(([0], np.cumsum(np.bincount(read_of, minlength=n_reads)[:n_reads]))).tolist()
+    return [pairs[bounds[r]:bounds[r + 1]] for r in range(n_reads)]
 
 
 def infer_packed(engine, packed, threshold=0.5, min_run=15, return_probs=False):

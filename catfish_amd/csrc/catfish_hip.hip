@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x_
 }
 
 #include "gru_bf16.hpp"
+#include "gru_bf16_pipe.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 3: head -- logits = p_fw + p_bw + b, probs = sigmoid (rnn_class.py:84,179-181),
@@ -1101,6 +1102,10 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_layer_bf16_kernel<32, true, 1>, gb_pack_bytes(32, 1));
         optin((const void*)gru_layer_bf16_kernel<128, false, 1>, gb_pack_bytes(128, 1));
         optin((const void*)gru_layer_bf16_kernel<128, true, 1>, gb_pack_bytes(128, 1));
+        optin((const void*)gru_bf16_pipe_kernel<32, false>, gb_pack_bytes(32, 1));
+        optin((const void*)gru_bf16_pipe_kernel<32, true>, gb_pack_bytes(32, 1));
+        optin((const void*)gru_bf16_pipe_kernel<128, false>, gb_pack_bytes(128, 1));
+        optin((const void*)gru_bf16_pipe_kernel<128, true>, gb_pack_bytes(128, 1));
         optin((const void*)gru_layer_bf16_kernel<32, false, 2>, gb_pack_bytes(32, 2));
         optin((const void*)gru_layer_bf16_kernel<32, true, 2>, gb_pack_bytes(32, 2));
         optin((const void*)gru_layer_bf16_kernel<128, false, 2>, gb_pack_bytes(128, 2));
@@ -1189,6 +1194,15 @@ static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
     if (rc != CF_OK) return rc;
+    static const int pipe_env = getenv("CATFISH_BF16_PIPE") ? atoi(getenv("CATFISH_BF16_PIPE")) : 1;   // A/B knob for tools/
+    if constexpr (NP == 1) {
+        if (pipe_env) {      // plain bf16: the software-pipelined kernel (vector work issued behind every MFMA)
+            hipLaunchKernelGGL((gru_bf16_pipe_kernel<CIN, LAST>), dim3(gx, 2), dim3(waves * 64), lds_bytes, s, wpack,
+                               reinterpret_cast<const bf16x8*>(X), reinterpret_cast<bf16x8*>(Y), P, n_tiles32);
+            HIP_TRY(hipGetLastError());
+            return prof_end(m, s, pi);
+        }
+    }
     hipLaunchKernelGGL((gru_layer_bf16_kernel<CIN, LAST, NP>), dim3(gx, 2), dim3(waves * 64), lds_bytes, s, wpack,
                        reinterpret_cast<const bf16x8*>(X), reinterpret_cast<bf16x8*>(Y), P, n_tiles32);
     HIP_TRY(hipGetLastError());
@@ -1754,10 +1768,15 @@ extern "C" const char* cf_profile_slot_name(int slot) {
 // ---- debug hook --------------------------------------------------------------------------
 extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host) {
     if (!m || !out_host) return fail(CF_ERR_INVALID, "cf_debug_stage: null argument");
-    if (m->np > 0) return fail(CF_ERR_INVALID, "cf_debug_stage: only available with CF_PREC_FP32");
+    if (m->np > 0 && stage != 100) return fail(CF_ERR_INVALID, "cf_debug_stage: only available with CF_PREC_FP32");
     const cf_model::Slot& sl = m->slots[0];
-    if (n_windows <= 0 || n_windows > sl.last_windows) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds slot 0's last pass");
+    if (n_windows <= 0 || (stage != 100 && n_windows > sl.last_windows)) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds slot 0's last pass");
     HIP_TRY(hipSetDevice(m->device));
+    if (stage == 100) {      // raw dense-partial buffer of slot 0 (diagnostic builds park their in-kernel stamps there)
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out_host, sl.d_p, (size_t)n_windows * sizeof(float), hipMemcpyDeviceToHost));
+        return CF_OK;
+    }
     int feats, mt;
     const float* src;
     if (stage >= 0 && stage < m->hp.n_layers_res) {
