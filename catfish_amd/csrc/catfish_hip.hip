@@ -246,6 +246,110 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel 1c: the first TWO residual blocks in one launch (throughput mode).  Block 1 runs one position behind
+// block 0 in the same stream, so block 0's 32-channel output goes from its accumulators straight into block 1's
+// first MFMAs (the accumulator layout is a B-operand layout, see the header) and never exists in HBM: 256 B per
+// sample of traffic and one launch less.  Same operations in the same order as two res_block_kernel launches:
+// bit-identical output.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict__ wpack0, const float* __restrict__ wpack1,
+                                                         const float* __restrict__ x_nat,   // [n_windows, 35]
+                                                         f32x4* __restrict__ y_frag,        // [tile][t][2][lane], block 1's output
+                                                         int64_t n_windows, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK0 = res_pack_floats(true), PACK1 = res_pack_floats(false);
+    constexpr int VEC0 = res_units(true) * 1024, VEC1 = res_units(false) * 1024;
+    {
+        const f32x4* src0 = reinterpret_cast<const f32x4*>(wpack0);
+        const f32x4* src1 = reinterpret_cast<const f32x4*>(wpack1);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < PACK0 / 4; i += blockDim.x) dst[i] = src0[i];
+        for (int i = threadIdx.x; i < PACK1 / 4; i += blockDim.x) dst[PACK0 / 4 + i] = src1[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4;
+    const int waves_per_block = blockDim.x >> 6;
+    const float* w0 = lds;                 // block 0: units {c3 tap0, tap1, tap2, last}; vectors {b_c3, b_last, w_sc, b_sc, w_first, b_first}
+    const float* w1 = lds + PACK0;         // block 1: units {sc, first, c3 tap0, tap1, tap2, last}; vectors {b_sc, b_first, b_c3, b_last}
+    float* xs = lds + PACK0 + PACK1 + wave * (CF_TILE * CF_T);      // this wave's x tile [16][35]
+    auto vec0 = [&](int v, int mo) -> f32x4 { return *reinterpret_cast<const f32x4*>(w0 + VEC0 + v * 32 + mo * 16 + q * 4); };
+    auto vec1 = [&](int v, int mo) -> f32x4 { return *reinterpret_cast<const f32x4*>(w1 + VEC1 + v * 32 + mo * 16 + q * 4); };
+    const f32x4 zero = {0, 0, 0, 0};
+
+    for (int tile = blockIdx.x * waves_per_block + wave; tile < n_tiles; tile += gridDim.x * waves_per_block) {
+        {
+            const int64_t base = (int64_t)tile * CF_TILE * CF_T;
+            const int64_t limit = n_windows * CF_T;
+            for (int i = lane; i < CF_TILE * CF_T; i += 64) xs[i] = (base + i < limit) ? x_nat[base + i] : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        f32x4 w_sc[2], b_sc[2], w_f[2], b_f[2];
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo) { w_sc[mo] = vec0(2, mo); b_sc[mo] = vec0(3, mo); w_f[mo] = vec0(4, mo); b_f[mo] = vec0(5, mo); }
+        f32x4 a_pp[2] = {zero, zero}, a_p[2] = {zero, zero}, a_sp[2] = {zero, zero};     // block 0: o1[t-1], o1[t], shortcut[t]
+        f32x4 b_pp[2] = {zero, zero}, b_p[2] = {zero, zero}, b_sp[2] = {zero, zero};     // block 1, one position behind
+        for (int i = 0; i <= CF_T + 1; ++i) {
+            // ---- block 0, front at position i: Cin = 1, conv1d is a rank-1 update (resnet_class.py:60,64)
+            f32x4 a_c[2] = {zero, zero}, a_sc[2] = {zero, zero};
+            if (i < CF_T) {
+                const float xv = xs[(lane & 15) * CF_T + i];
+#pragma unroll
+                for (int mo = 0; mo < 2; ++mo) {
+                    a_sc[mo] = w_sc[mo] * xv + b_sc[mo];
+                    a_c[mo] = relu4(w_f[mo] * xv + b_f[mo]);
+                }
+            }
+            // ---- block 0, back: its output at position i - 1 stays in registers as block 1's input
+            f32x4 y0[2] = {zero, zero};
+            const bool have_y0 = i >= 1 && i <= CF_T;
+            if (have_y0) {
+                f32x4 acc[2] = {vec0(0, 0), vec0(0, 1)};
+                unit_mma(w0 + 0 * 1024, lane, a_pp, acc);                 // tap 0 * o1[t-1]
+                unit_mma(w0 + 1 * 1024, lane, a_p, acc);                  // tap 1 * o1[t]
+                unit_mma(w0 + 2 * 1024, lane, a_c, acc);                  // tap 2 * o1[t+1]
+                f32x4 o2[2] = {relu4(acc[0]), relu4(acc[1])};             // (:69-71)
+                f32x4 acc3[2] = {vec0(1, 0), vec0(1, 1)};
+                unit_mma(w0 + 3 * 1024, lane, o2, acc3);                  // last conv (:74-76)
+                y0[0] = relu4(relu4(acc3[0]) + a_sp[0]);                  // add + relu (:79-80)
+                y0[1] = relu4(relu4(acc3[1]) + a_sp[1]);
+            }
+            // ---- block 1, front at position p = i - 1 (zero padding past the window end, p = T)
+            f32x4 b_c[2] = {zero, zero}, b_sc[2] = {zero, zero};
+            if (have_y0) {
+                b_sc[0] = vec1(0, 0); b_sc[1] = vec1(0, 1);
+                unit_mma(w1 + 0 * 1024, lane, y0, b_sc);                  // shortcut, no relu (:60-61)
+                f32x4 acc[2] = {vec1(1, 0), vec1(1, 1)};
+                unit_mma(w1 + 1 * 1024, lane, y0, acc);                   // first conv (:64-66)
+                b_c[0] = relu4(acc[0]); b_c[1] = relu4(acc[1]);
+            }
+            // ---- block 1, back: output position p - 1 = i - 2
+            if (i >= 2) {
+                f32x4 acc[2] = {vec1(2, 0), vec1(2, 1)};
+                unit_mma(w1 + 2 * 1024, lane, b_pp, acc);
+                unit_mma(w1 + 3 * 1024, lane, b_p, acc);
+                unit_mma(w1 + 4 * 1024, lane, b_c, acc);
+                f32x4 o2[2] = {relu4(acc[0]), relu4(acc[1])};
+                f32x4 acc3[2] = {vec1(3, 0), vec1(3, 1)};
+                unit_mma(w1 + 5 * 1024, lane, o2, acc3);
+                f32x4* dst = y_frag + ((int64_t)tile * CF_T + (i - 2)) * 2 * 64 + lane;
+                dst[0] = relu4(relu4(acc3[0]) + b_sp[0]);
+                dst[64] = relu4(relu4(acc3[1]) + b_sp[1]);
+            }
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo) {
+                a_pp[mo] = a_p[mo]; a_p[mo] = a_c[mo]; a_sp[mo] = a_sc[mo];
+                if (i >= 1) { b_pp[mo] = b_p[mo]; b_p[mo] = b_c[mo]; b_sp[mo] = b_sc[mo]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 2: one bidirectional GRU layer (rnn_class.py:142-148,165-171), both
 // directions in one grid (blockIdx.y).  A workgroup stages its direction's
 // packed weights in LDS once; each wave then owns tiles of 16 windows and runs
@@ -758,10 +862,10 @@ static int fail(int code, const std::string& msg) {
             return fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
-enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_NORM, SLOT_GRU_FUSED };
+enum { SLOT_RES_FIRST = 0, SLOT_RES, SLOT_GRU0, SLOT_GRU, SLOT_GRU_LAST, SLOT_HEAD, SLOT_POST, SLOT_NORM, SLOT_GRU_FUSED, SLOT_RES_STACK2 };
 static const char* k_slot_names[CF_PROF_SLOTS] = {"res_block_first", "res_block",      "gru_layer_first", "gru_layer_mid",
                                                   "gru_layer_last",  "head",           "postprocess",     "normalize",       "gru_fused",
-                                                  "unused",          "unused",         "unused"};
+                                                  "res_stack2",      "unused",         "unused"};
 
 struct cf_model {
     cf_hparams hp;
@@ -788,6 +892,7 @@ struct cf_model {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
         int64_t last_windows = 0;             // windows of the last pass (debug hook)
+        bool last_res_fused = false;          // the last pass ran blocks 0 and 1 as one launch: block 0's output was never stored
     };
     std::vector<Slot> slots;
     int fuse = 0;                             // all GRU layers in one launch (fp32 path, n_layers <= 3): 0 never, 1 always,
@@ -1096,6 +1201,7 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_train_fwd_kernel<128>, gru_pack_floats(128) * 4);
         optin((const void*)gru_train_bwd_kernel<32>, gtb_pack_floats(32) * 4);
         optin((const void*)gru_train_bwd_kernel<128>, gtb_pack_floats(128) * 4);
+        optin((const void*)res_stack2_kernel, (res_pack_floats(true) + res_pack_floats(false) + 4 * CF_TILE * CF_T) * 4);
         optin((const void*)res_train_fwd_kernel, RT_FWD_LDS_BYTES);
         optin((const void*)res_train_bwd_kernel, RT_BWD_LDS_BYTES);
         optin((const void*)gru_layer_bf16_kernel<32, false, 1>, gb_pack_bytes(32, 1));
@@ -1233,7 +1339,20 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     const int res_chunks = res_split ? 4 : 1;
     const int res_waves = res_split ? 4 : (pick_waves(n_tiles, m->n_cu * 2) > 4 ? 4 : pick_waves(n_tiles, m->n_cu * 2));
     const int res_grid = res_split ? n_tiles : std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
-    for (int b = 0; b < m->hp.n_layers_res; ++b) {
+    // throughput mode (fp32): the first two blocks as ONE launch, block 0's output stays in registers
+    static const int res_fuse_env = getenv("CATFISH_RES_FUSE") ? atoi(getenv("CATFISH_RES_FUSE")) : 1;   // A/B knob for tools/
+    const bool res_fused = m->np == 0 && !res_split && m->hp.n_layers_res >= 2 && res_fuse_env != 0;
+    sl.last_res_fused = res_fused;
+    if (res_fused) {
+        if ((rc = prof_begin(m, SLOT_RES_STACK2, s, &pi)) != CF_OK) return rc;
+        const int lds_bytes = (res_pack_floats(true) + res_pack_floats(false) + res_waves * CF_TILE * CF_T) * 4;
+        const int grid2 = std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 3);     // 51 KB of LDS: three workgroups per CU
+        hipLaunchKernelGGL(res_stack2_kernel, dim3(grid2), dim3(res_waves * 64), lds_bytes, s, m->d_res[0], m->d_res[1], x,
+                           reinterpret_cast<f32x4*>(sl.d_a[1]), n_windows, n_tiles);
+        HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+    }
+    for (int b = res_fused ? 2 : 0; b < m->hp.n_layers_res; ++b) {
         float* dst = sl.d_a[b & 1];
         if (m->np > 0) {
             // residual blocks on the bf16 matrix pipe, 32-window tiles
@@ -1782,6 +1901,8 @@ extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* 
     if (stage >= 0 && stage < m->hp.n_layers_res) {
         // ping-pong: only the last two blocks survive a pass
         if (stage < m->hp.n_layers_res - 2) return fail(CF_ERR_INVALID, "cf_debug_stage: stage overwritten");
+        if (stage == 0 && sl.last_res_fused)
+            return fail(CF_ERR_INVALID, "cf_debug_stage: block 0's output is not materialised by the fused two-block launch (throughput mode)");
         feats = CF_C; mt = 2; src = sl.d_a[stage & 1];
     } else if (stage >= m->hp.n_layers_res && stage < m->hp.n_layers_res + m->hp.n_layers - 1) {
         const int l = stage - m->hp.n_layers_res;

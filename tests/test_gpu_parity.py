@@ -116,11 +116,22 @@ def test_throughput_kernel_at_benchmark_size(ckpt_weights, n_windows):
     eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=32768)
     try:
         got = eng.infer_host(x).reshape(n_windows, 35)
+        # throughput mode runs residual blocks 0 and 1 as ONE launch: block 1's output is checked against the oracle,
+        # block 0's is never stored
+        res1 = eng.debug_stage(1, 48)
+        with pytest.raises(ValueError, match="not materialised"):
+            eng.debug_stage(0, 48)
         idx = np.concatenate([np.arange(n_windows - 48, n_windows), rng.integers(0, n_windows - 48, size=80)])
-        small = eng.infer_host(x[idx]).reshape(len(idx), 35)        # 128 windows: latency-mode kernels
+        small = eng.infer_host(x[idx]).reshape(len(idx), 35)        # 128 windows: latency-mode kernels (one launch per block)
+        res1_small = eng.debug_stage(1, 128)
+        eng.infer_host(x[:48])
+        assert np.array_equal(eng.debug_stage(1, 48), res1)         # fused two-block launch == two launches, bit for bit
+        assert eng.debug_stage(0, 48).shape == (48, 35, 32)
     finally:
         eng.close()
-    want = oracle.forward(x[idx], ckpt_weights, np.float64).reshape(len(idx), 35)
+    want, stages = oracle.forward(x[idx], ckpt_weights, np.float64, return_stages=True)
+    want = want.reshape(len(idx), 35)
+    assert np.abs(res1_small - stages["res1"]).max() < 2e-5
     assert np.abs(got[idx] - want).max() < TOL
     assert np.array_equal(got[idx], small)                          # every regime gives the same bits
     assert np.isfinite(got).all()
