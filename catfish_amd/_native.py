@@ -80,6 +80,12 @@ SYMBOLS = {
                                        C.c_void_p]),
     "cf_gru_train_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cf_gru_train_forward_dropout": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_float, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "cf_gru_train_backward_dropout": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_int32,
+                                                C.c_void_p, C.c_void_p]),
+    "cf_dropout_scale": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cf_gru_wgrad_workspace_floats": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64]),
     "cf_gru_train_wgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -88,6 +94,11 @@ SYMBOLS = {
     "cf_res_train_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cf_res_train_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_int64, C.c_void_p]),
+    "cf_train_head_workspace_floats": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "cf_train_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cf_opt_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cf_profile_reset": (C.c_int, [C.c_void_p]),
     "cf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

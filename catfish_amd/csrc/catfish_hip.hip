@@ -102,6 +102,37 @@ __device__ __forceinline__ f32x4 cf_sigmoid_pre4(f32x4 a) {
 __device__ __forceinline__ f32x4 cf_tanh_pre4(f32x4 a) {
     return __builtin_elementwise_fma((f32x4){-2.0f, -2.0f, -2.0f, -2.0f}, cf_sigmoid_pre4(a), (f32x4){1.0f, 1.0f, 1.0f, 1.0f});
 }
+// Output dropout of the training kernels (DropoutWrapper(output_keep_prob), rnn_class.py:151-154) without a stored mask: whether
+// element e of a layer's output survives is a hash of (seed, layer, optimizer step, e), evaluated where the value is produced
+// (forward: the dropped copy the next layer reads) and again where its gradient arrives (backward).  keep_prob >= 1: off.
+struct cf_dropout {
+    float keep_prob = 1.f;
+    uint32_t seed = 0;
+    int32_t layer = 0;
+    const double* step = nullptr;      // device: optimizer steps taken so far (a new mask every step, also under graph replay)
+};
+__device__ __forceinline__ uint32_t cf_fmix32(uint32_t v) {      // murmur3 finalizer: full avalanche on 32 bits
+    v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+    return v;
+}
+__device__ __forceinline__ uint32_t cf_drop_key(const cf_dropout& d) {
+    const uint32_t st = d.step ? (uint32_t)(long long)d.step[0] : 0u;
+    return cf_fmix32(d.seed ^ cf_fmix32(0x9E3779B9u * (uint32_t)(d.layer + 1) + st * 0x85ebca6bu));
+}
+// mask / keep_prob of the four elements of f32x4 number idx4 of a layer output [tile][t][8][lane]
+__device__ __forceinline__ f32x4 cf_drop_scale4(uint32_t key, float keep_prob, int64_t idx4) {
+    const uint32_t thresh = (uint32_t)fminf(keep_prob * 4294967296.0f, 4294967040.0f);
+    const float inv = 1.0f / keep_prob;
+    const uint64_t e = (uint64_t)idx4 * 4u;
+    const uint32_t base = (uint32_t)e ^ ((uint32_t)(e >> 32) * 0x9E3779B9u);
+    f32x4 o;
+    o.x = cf_fmix32((base + 0u) ^ key) < thresh ? inv : 0.f;
+    o.y = cf_fmix32((base + 1u) ^ key) < thresh ? inv : 0.f;
+    o.z = cf_fmix32((base + 2u) ^ key) < thresh ? inv : 0.f;
+    o.w = cf_fmix32((base + 3u) ^ key) < thresh ? inv : 0.f;
+    return o;
+}
+
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     f32x4 o;
     o.x = fmaxf(v.x, 0.f); o.y = fmaxf(v.y, 0.f); o.z = fmaxf(v.z, 0.f); o.w = fmaxf(v.w, 0.f);
@@ -384,7 +415,8 @@ __device__ __forceinline__ void gru_stage_weights(float* lds, const float* __res
 template <int CIN, bool LAST, bool STASH = false>
 __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, int tile, const f32x4* __restrict__ X,
                                          f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
-                                         f32x4* __restrict__ S = nullptr) {
+                                         f32x4* __restrict__ S = nullptr, f32x4* __restrict__ YD = nullptr, cf_dropout drop = cf_dropout()) {
+    const uint32_t drop_key = (STASH && YD) ? cf_drop_key(drop) : 0u;
     constexpr int KGX = CIN / 16;   // f32x4 registers of x per lane and step
     constexpr int KSX = CIN / 4;    // k-steps of the x part
     constexpr int XN4 = gru_x_floats(CIN) / 4;        // region sizes in f32x4 units
@@ -504,6 +536,13 @@ __device__ __forceinline__ void gru_tile(const float* lds, int lane, int dir, in
                 f32x4* dst = Y + (((int64_t)tile * CF_T + t) * 8 + dir * 4) * 64 + lane;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) if (!(CF_ABLATE & 2) || s == CF_T - 1) dst[m * 64] = h[m];
+                if constexpr (STASH) {
+                    if (YD) {       // training with dropout: the copy the next layer (or the dense head) reads
+                        const int64_t i0 = (((int64_t)tile * CF_T + t) * 8 + dir * 4) * 64 + lane;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) YD[i0 + m * 64] = h[m] * cf_drop_scale4(drop_key, drop.keep_prob, i0 + m * 64);
+                    }
+                }
             } else {
                 // partial logit of this direction: sum_f w[f] * h[f]   (final_fully_connected/MatMul)
                 // summation order shared with the cooperative kernel (bit-identical results): one fma chain per
@@ -646,6 +685,7 @@ static_assert(gtb_pack_floats(32) == ((32 + CF_H) / 16 / 2) * 128 * 48 && gtb_pa
 #define CF_COOP_BWD_XCH_FLOATS (3 * 4 * 64 * 4)   // da_c, da_r, da_u exchange tiles
 #include "gru_wgrad.hpp"
 #include "res_train.hpp"
+#include "train_step.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1b: plain RNN type (no residual blocks, rnn_class.py:165-175 applied to the raw signal).
@@ -1653,9 +1693,22 @@ static int train_cin_ok(const cf_model* m, int cin) {
     return CF_OK;
 }
 
-extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag, float* stash,
-                                    int64_t n_windows, void* stream) {
+static cf_dropout make_dropout(float keep_prob, uint32_t seed, int32_t layer, const double* step_count) {
+    cf_dropout d;
+    d.keep_prob = keep_prob;
+    d.seed = seed;
+    d.layer = layer;
+    d.step = step_count;
+    return d;
+}
+
+extern "C" int cf_gru_train_forward_dropout(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag, float* stash,
+                                            int64_t n_windows, float* y_drop_frag, float keep_prob, uint32_t seed, int32_t layer,
+                                            const double* step_count, void* stream) {
     if (!m || !wpack || !x_frag || !y_frag || !stash) return fail(CF_ERR_INVALID, "cf_gru_train_forward: null argument");
+    if (y_drop_frag && !(keep_prob > 0.f && keep_prob < 1.f)) return fail(CF_ERR_INVALID, "cf_gru_train_forward_dropout: keep_prob must be in (0, 1)");
+    f32x4* yd = reinterpret_cast<f32x4*>(y_drop_frag);
+    const cf_dropout drop = make_dropout(y_drop_frag ? keep_prob : 1.f, seed, layer, step_count);
     if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_forward: n_windows must be positive");
     int rc = train_cin_ok(m, cin);
     if (rc != CF_OK) return rc;
@@ -1671,13 +1724,13 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
                 hipLaunchKernelGGL((gru_xproj_kernel<32>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
                                    reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
-                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp);
+                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp, yd, drop);
         } else {
             if (hoist)
                 hipLaunchKernelGGL((gru_xproj_kernel<128>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
                                    reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
-                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp);
+                               reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp, yd, drop);
         }
         HIP_TRY(hipGetLastError());
         return CF_OK;
@@ -1686,17 +1739,24 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
     const int gx = std::min((n_tiles + waves - 1) / waves, std::max(1, m->n_cu / 2));
     if (cin == CF_C)
         hipLaunchKernelGGL((gru_train_fwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(32) * 4, s, wpack,
-                           reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+                           reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, yd, drop);
     else
         hipLaunchKernelGGL((gru_train_fwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gru_pack_floats(128) * 4, s, wpack,
-                           reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles);
+                           reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, yd, drop);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }
 
-extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
-                                     const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
-                                     int64_t n_windows, void* stream) {
+extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag, float* stash,
+                                    int64_t n_windows, void* stream) {
+    return cf_gru_train_forward_dropout(m, cin, wpack, x_frag, y_frag, stash, n_windows, nullptr, 1.f, 0u, 0, nullptr, stream);
+}
+
+extern "C" int cf_gru_train_backward_dropout(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
+                                             const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
+                                             int64_t n_windows, float keep_prob, uint32_t seed, int32_t layer, const double* step_count,
+                                             void* stream) {
+    const cf_dropout drop = make_dropout((keep_prob > 0.f && keep_prob < 1.f) ? keep_prob : 1.f, seed, layer, step_count);
     if (!m || !wpack_bwd || !y_frag || !stash || !dy_frag || !dx_frag || !da)
         return fail(CF_ERR_INVALID, "cf_gru_train_backward: null argument");
     if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_gru_train_backward: n_windows must be positive");
@@ -1712,7 +1772,7 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
-                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer);
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer, drop);
             if (defer)
                 hipLaunchKernelGGL((gru_dx_kernel<32>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
                                    reinterpret_cast<f32x4*>(dx_frag), n_tiles, cf_xproj_chunks(n_tiles));
@@ -1720,7 +1780,7 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
-                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer);
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer, drop);
             if (defer)
                 hipLaunchKernelGGL((gru_dx_kernel<128>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
                                    reinterpret_cast<f32x4*>(dx_frag), n_tiles, cf_xproj_chunks(n_tiles));
@@ -1734,12 +1794,38 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
         hipLaunchKernelGGL((gru_train_bwd_kernel<32>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(32) * 4, s, wpack_bwd,
                            reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                            reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
-                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, drop);
     else
         hipLaunchKernelGGL((gru_train_bwd_kernel<128>), dim3(gx, 2), dim3(waves * 64), gtb_pack_floats(128) * 4, s, wpack_bwd,
                            reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                            reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
-                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles);
+                               reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, drop);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
+                                     const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
+                                     int64_t n_windows, void* stream) {
+    return cf_gru_train_backward_dropout(m, cin, wpack_bwd, y_frag, stash, dy_frag, dy2_frag, dy_scale, dx_frag, da, n_windows, 1.f, 0u, 0,
+                                         nullptr, stream);
+}
+
+// The mask / keep_prob tensor the training kernels apply to the output of `layer` (fragment layout [tiles][35][8][64][4]), written out
+// for tests and tools: the kernels themselves never store it.
+__global__ __launch_bounds__(256) void dropout_scale_kernel(f32x4* __restrict__ out, int64_t n4, cf_dropout drop) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) out[i] = cf_drop_scale4(cf_drop_key(drop), drop.keep_prob, i);
+}
+
+extern "C" int cf_dropout_scale(cf_model* m, float keep_prob, uint32_t seed, int32_t layer, const double* step_count, int64_t n_windows,
+                                float* scale_frag, void* stream) {
+    if (!m || !scale_frag) return fail(CF_ERR_INVALID, "cf_dropout_scale: null argument");
+    if (!(keep_prob > 0.f && keep_prob < 1.f) || n_windows <= 0) return fail(CF_ERR_INVALID, "cf_dropout_scale: keep_prob must be in (0, 1), n_windows > 0");
+    HIP_TRY(hipSetDevice(m->device));
+    const int64_t n4 = ((n_windows + CF_TILE - 1) / CF_TILE) * CF_T * 8 * 64;
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<f32x4*>(scale_frag), n4, make_dropout(keep_prob, seed, layer, step_count));
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }
@@ -1839,6 +1925,59 @@ extern "C" int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float*
     HIP_TRY(hipGetLastError());
     const int nf = L.off[4 * n_blocks];
     hipLaunchKernelGGL(res_train_reduce_kernel, dim3((nf + 63) / 64), dim3(256), 0, s, workspace, grads, nf, n_wg);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+// ---- dense head + loss, optimizer (training) ------------------------------------------------
+static int head_waves(const cf_model* m, int64_t n_windows) {
+    const int64_t items = ((n_windows + CF_TILE - 1) / CF_TILE) * CF_T;
+    const int64_t wgs = std::min<int64_t>((items + 3) / 4, (int64_t)m->n_cu * 2);
+    return (int)std::max<int64_t>(1, wgs) * 4;
+}
+
+extern "C" int64_t cf_train_head_workspace_floats(cf_model* m, int64_t n_windows) {
+    if (!m || n_windows <= 0) return 0;
+    return (int64_t)head_waves(m, n_windows) * CF_HEAD_PART;
+}
+
+extern "C" int cf_train_head(cf_model* m, const float* y_frag, const float* dense_kernel, const float* dense_bias, const float* labels,
+                             int64_t n_windows, float* dy_frag, float* logits, float* workspace, int64_t workspace_floats, float* grads,
+                             float* loss, void* stream) {
+    if (!m || !y_frag || !dense_kernel || !dense_bias || !labels || !dy_frag || !workspace || !grads || !loss)
+        return fail(CF_ERR_INVALID, "cf_train_head: null argument");
+    if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_train_head: n_windows must be positive");
+    if (workspace_floats < cf_train_head_workspace_floats(m, n_windows))
+        return fail(CF_ERR_INVALID, "cf_train_head: workspace too small (see cf_train_head_workspace_floats)");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n_tiles = (int)((n_windows + CF_TILE - 1) / CF_TILE);
+    const int waves = head_waves(m, n_windows);
+    const float inv_count = (float)(1.0 / ((double)n_windows * CF_T));
+    hipLaunchKernelGGL(train_head_kernel, dim3(waves / 4), dim3(256), 0, s, reinterpret_cast<const f32x4*>(y_frag), dense_kernel, dense_bias,
+                       labels, reinterpret_cast<f32x4*>(dy_frag), logits, workspace, n_windows, n_tiles, inv_count);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(train_head_reduce_kernel, dim3(3), dim3(256), 0, s, workspace, waves, grads, loss, inv_count);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+extern "C" int cf_opt_step(cf_model* m, int32_t kind, float* params, const float* grads, float* slot1, float* slot2, int64_t n, float lr,
+                           double* step_count, const int32_t* pack_idx, const float* pack_scale, float* packed, int64_t n_packed,
+                           void* stream) {
+    if (!m || !params || !grads || !slot1 || !slot2 || !step_count) return fail(CF_ERR_INVALID, "cf_opt_step: null argument");
+    if (kind != 0 && kind != 1) return fail(CF_ERR_INVALID, "cf_opt_step: kind must be 0 (RMSProp) or 1 (Adam)");
+    if (n <= 0 || n_packed < 0) return fail(CF_ERR_INVALID, "cf_opt_step: bad size");
+    if (n_packed > 0 && (!pack_idx || !pack_scale || !packed)) return fail(CF_ERR_INVALID, "cf_opt_step: null packing argument");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(opt_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int)kind, params, grads, slot1, slot2, n, lr,
+                       step_count);
+    HIP_TRY(hipGetLastError());
+    // the re-tiling launch also advances the step counter (it runs after every block of the update has read it)
+    const int64_t ng = std::max<int64_t>(n_packed, 1);
+    hipLaunchKernelGGL(gather_scale_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, params, pack_idx, pack_scale, packed, n_packed,
+                       step_count);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }

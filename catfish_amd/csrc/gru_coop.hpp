@@ -22,7 +22,9 @@ static inline int cf_xproj_chunks(int n_tiles) { return n_tiles <= 8 ? CF_T : 7;
 template <int CIN, bool LAST, int W, bool STASH = false, bool HOIST = false>
 __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ X,
                                               f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,
-                                              f32x4* __restrict__ S = nullptr, const f32x4* __restrict__ XP = nullptr) {
+                                              f32x4* __restrict__ S = nullptr, const f32x4* __restrict__ XP = nullptr,
+                                              f32x4* __restrict__ YD = nullptr, cf_dropout drop = cf_dropout()) {
+    const uint32_t drop_key = (STASH && YD) ? cf_drop_key(drop) : 0u;
     constexpr int KGX = CIN / 16;
     constexpr int KSX = HOIST ? 0 : CIN / 4;          // k-steps of the x part done in this kernel
     constexpr int XOFF = CIN / 4;                     // k-steps the packed x region holds
@@ -144,6 +146,12 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
         hx[W * 64] = hown;
         if constexpr (!LAST) {
             Y[(((int64_t)tile * CF_T + t) * 8 + dir * 4 + W) * 64 + lane] = hown;
+            if constexpr (STASH) {
+                if (YD) {           // training with dropout: the copy the next layer (or the dense head) reads
+                    const int64_t i0 = (((int64_t)tile * CF_T + t) * 8 + dir * 4 + W) * 64 + lane;
+                    YD[i0] = hown * cf_drop_scale4(drop_key, drop.keep_prob, i0);
+                }
+            }
         } else {
             const f32x4 wd = *(reinterpret_cast<const f32x4*>(lds + DENSE) + q + W * 4);
             float p = wd.x * hown.x;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __r
 template <int CIN>
 __global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
                                                                     f32x4* __restrict__ Y, f32x4* __restrict__ S, int n_tiles,
-                                                                    const f32x4* __restrict__ XP) {
+                                                                    const f32x4* __restrict__ XP, f32x4* __restrict__ YD, cf_dropout drop) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = gru_pack_floats(CIN);
     const int dir = blockIdx.y;
@@ -261,17 +269,17 @@ __global__ __launch_bounds__(256, 1) void gru_train_fwd_coop_kernel(const float*
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (XP) {
             switch (wave) {
-                case 0: gru_tile_coop<CIN, false, 0, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
-                case 1: gru_tile_coop<CIN, false, 1, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
-                case 2: gru_tile_coop<CIN, false, 2, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
-                default: gru_tile_coop<CIN, false, 3, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP); break;
+                case 0: gru_tile_coop<CIN, false, 0, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP, YD, drop); break;
+                case 1: gru_tile_coop<CIN, false, 1, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP, YD, drop); break;
+                case 2: gru_tile_coop<CIN, false, 2, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP, YD, drop); break;
+                default: gru_tile_coop<CIN, false, 3, true, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, XP, YD, drop); break;
             }
         } else {
             switch (wave) {
-                case 0: gru_tile_coop<CIN, false, 0, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
-                case 1: gru_tile_coop<CIN, false, 1, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
-                case 2: gru_tile_coop<CIN, false, 2, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
-                default: gru_tile_coop<CIN, false, 3, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S); break;
+                case 0: gru_tile_coop<CIN, false, 0, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, nullptr, YD, drop); break;
+                case 1: gru_tile_coop<CIN, false, 1, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, nullptr, YD, drop); break;
+                case 2: gru_tile_coop<CIN, false, 2, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, nullptr, YD, drop); break;
+                default: gru_tile_coop<CIN, false, 3, true>(lds, xch, lane, dir, tile, X, Y, nullptr, n_tiles, S, nullptr, YD, drop); break;
             }
         }
         __syncthreads();
@@ -291,7 +299,9 @@ template <int CIN, int W, bool DEFER = false>
 __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, int lane, int dir, int tile, const f32x4* __restrict__ Y,
                                                   const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
                                                   const f32x4* __restrict__ DY2, const f32x4* __restrict__ DSC, f32x4* __restrict__ DX,
-                                                  f32x4* __restrict__ DA, int n_tiles) {
+                                                  f32x4* __restrict__ DA, int n_tiles, cf_dropout drop) {
+    const bool drop_on = !DSC && drop.keep_prob < 1.f;      // the layer's output dropout, mask recomputed (no stored mask)
+    const uint32_t drop_key = drop_on ? cf_drop_key(drop) : 0u;
     constexpr int MI = (CIN + CF_H) / 16;
     constexpr int MX = CIN / 16;
     constexpr int NXW = DEFER ? 0 : (MX > W ? (MX - W + 3) / 4 : 0);     // x-row tiles of this wave: W, W+4, ...
@@ -328,6 +338,7 @@ __device__ __forceinline__ void gru_bwd_tile_coop(const float* lds, float* xch, 
         f32x4 dy = DY[(base * 8 + dir * 4 + W) * 64 + lane];
         if (DY2) dy += DY2[(base * 8 + dir * 4 + W) * 64 + lane];
         if (DSC) dy *= DSC[(base * 8 + dir * 4 + W) * 64 + lane];
+        else if (drop_on) dy *= cf_drop_scale4(drop_key, drop.keep_prob, (base * 8 + dir * 4 + W) * 64 + lane);
         const f32x4 dh = dhc + dy;
         f32x4 hp = {0, 0, 0, 0};
         if (s > 0) hp = Y[(((int64_t)tile * CF_T + tp) * 8 + dir * 4 + W) * 64 + lane];
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float*
                                                                     const f32x4* __restrict__ S, const f32x4* __restrict__ DY,
                                                                     const f32x4* __restrict__ DY2, const f32x4* __restrict__ DSC,
                                                                     f32x4* __restrict__ DX, f32x4* __restrict__ DA, int n_tiles,
-                                                                    int defer_dx) {
+                                                                    int defer_dx, cf_dropout drop) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK = ((CIN + CF_H) / 16 / 2) * 128 * 48;      // = gtb_pack_floats(CIN)
     const int dir = blockIdx.y;
@@ -409,17 +420,17 @@ __global__ __launch_bounds__(256, 1) void gru_train_bwd_coop_kernel(const float*
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (defer_dx) {
             switch (wave) {
-                case 0: gru_bwd_tile_coop<CIN, 0, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-                case 1: gru_bwd_tile_coop<CIN, 1, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-                case 2: gru_bwd_tile_coop<CIN, 2, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-                default: gru_bwd_tile_coop<CIN, 3, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                case 0: gru_bwd_tile_coop<CIN, 0, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
+                case 1: gru_bwd_tile_coop<CIN, 1, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
+                case 2: gru_bwd_tile_coop<CIN, 2, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
+                default: gru_bwd_tile_coop<CIN, 3, true>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
             }
         } else {
             switch (wave) {
-                case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-                case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-                case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
-                default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles); break;
+                case 0: gru_bwd_tile_coop<CIN, 0>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
+                case 1: gru_bwd_tile_coop<CIN, 1>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
+                case 2: gru_bwd_tile_coop<CIN, 2>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
+                default: gru_bwd_tile_coop<CIN, 3>(lds, xch, lane, dir, tile, Y, S, DY, DY2, DSC, DX, DA, n_tiles, drop); break;
             }
         }
     }

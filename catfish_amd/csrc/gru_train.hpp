@@ -26,7 +26,8 @@ __host__ __device__ constexpr int gtb_pack_floats(int cin) { return gtb_c_floats
 
 template <int CIN>
 __global__ __launch_bounds__(512, 2) void gru_train_fwd_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
-                                                               f32x4* __restrict__ Y, f32x4* __restrict__ S, int n_tiles) {
+                                                               f32x4* __restrict__ Y, f32x4* __restrict__ S, int n_tiles,
+                                                               f32x4* __restrict__ YD, cf_dropout drop) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int dir = blockIdx.y;
     gru_stage_weights<CIN>(lds, wpack, dir);
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(512, 2) void gru_train_fwd_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves)
-        gru_tile<CIN, false, true>(lds, lane, dir, tile, X, Y, nullptr, n_tiles, S);
+        gru_tile<CIN, false, true>(lds, lane, dir, tile, X, Y, nullptr, n_tiles, S, YD, drop);
 }
 
 template <int CIN>
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
                                                                const f32x4* __restrict__ DSC,     // optional per-element scale of dY (dropout mask / keep_prob)
                                                                f32x4* __restrict__ DX,            // [2 dirs][tile][t][CIN/16][lane]
                                                                f32x4* __restrict__ DA,            // [tile][t][2][12][lane]: da_r, da_u (0..7), da_c (8..11)
-                                                               int n_tiles) {
+                                                               int n_tiles, cf_dropout drop) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MI = gtb_mi(CIN);
     constexpr int MX = CIN / 16;            // x-row M-tiles; the 4 h-row M-tiles follow
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const far_lds<f32x2> WT(reinterpret_cast<const f32x2*>(lds) + lane);   // candidate region + (ks*(MI/2) + mi2)*64 | gate region
+    const bool drop_on = !DSC && drop.keep_prob < 1.f;      // the layer's output dropout, mask recomputed (no stored mask)
+    const uint32_t drop_key = drop_on ? cf_drop_key(drop) : 0u;
 
     for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves) {
         f32x4 dhc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // gradient carried to the previous step
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(512, 2) void gru_train_bwd_kernel(const float* __re
                     f32x4 dy = dyp[m * 64];
                     if (DY2) dy += DY2[(base * 8 + dir * 4 + m) * 64 + lane];
                     if (DSC) dy *= DSC[(base * 8 + dir * 4 + m) * 64 + lane];
+                    else if (drop_on) dy *= cf_drop_scale4(drop_key, drop.keep_prob, (base * 8 + dir * 4 + m) * 64 + lane);
                     dh[m] = dhc[m] + dy;
                 }
                 if (s > 0) {

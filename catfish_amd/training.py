@@ -238,9 +238,11 @@ class TFOptimizer(object):
 class Trainer(object):
     """One training step = forward + backward + optimizer update.
 
-    On a GPU the whole step (thousands of tiny recurrent kernels) is launch-bound in eager mode, so it is
-    captured ONCE into a HIP graph (``torch.cuda.CUDAGraph``) and replayed per batch; batches are copied into
-    static input buffers.  Dropout inside the graph draws from torch's default (graph-safe) CUDA generator.
+    On a GPU with the ResNetRNN type the step runs entirely on the HIP training kernels through the C ABI
+    (``catfish_amd/native_step.py``: conv stack, biGRU layers, dense head + loss, optimizer; no autograd), captured ONCE
+    into a HIP graph (``torch.cuda.CUDAGraph``) and replayed per batch; batches are copied into static input buffers.
+    Dropout masks inside the graph come from torch's default (graph-safe) CUDA generator.  ``native=False`` (and the CPU)
+    run the torch-autograd restatement of the same graph -- the reference the native step is tested against.
     """
 
     def __init__(self, weights, n_layers, n_layers_res, optimizer_choice, learning_rate, keep_prob, device=None,
@@ -260,13 +262,17 @@ class Trainer(object):
         if seed is not None:
             self.gen.manual_seed(int(seed))
         self.last_loss = None
-        # native = biGRU layers on the HIP training kernels (default on a GPU for the shipped geometry)
+        # native = the whole step on the HIP training kernels, no autograd (default on a GPU for the ResNetRNN type)
         self.native = (self.net.device.type == "cuda" and n_layers_res > 0) if native is None else bool(native)
         self.engine = None
+        self.step_impl = None
         if self.native:
             from .engine import HipEngine
             self.engine = HipEngine(weights, n_layers=n_layers, n_layers_res=n_layers_res,
                                     device=self.net.device.index or 0, max_windows_per_pass=256, fuse_layers=False)
+            if n_layers_res > 0 and self.net.dtype == torch.float32:
+                from .native_step import NativeTrainStep
+                self.step_impl = NativeTrainStep(self.net, self.opt, self.engine, self.keep_prob, seed=seed)
         self.use_graph = (self.net.device.type == "cuda") if use_graph is None else bool(use_graph)
         self._graph = None
         self._static = None
@@ -275,11 +281,24 @@ class Trainer(object):
 
     def _capture(self, x, y):
         torch = self.torch_mod = __import__("torch")
-        sx = torch.zeros(tuple(np.asarray(x).reshape(-1, 35).shape), dtype=self.net.dtype, device=self.net.device)
-        sy = torch.zeros_like(sx)
-        self.opt.keep_grads = True
+        shape = tuple(np.asarray(x).reshape(-1, 35).shape)
         side = torch.cuda.Stream(self.net.device)
         side.wait_stream(torch.cuda.current_stream(self.net.device))
+        if self.step_impl is not None:
+            # native step: every launch goes through the C ABI on the capture stream; buffers are static per batch size
+            b = self.step_impl._alloc(shape[0])
+            with torch.cuda.stream(side):                   # warm-up off the capture stream (allocator, lazy init); no update
+                for _ in range(2):
+                    self.step_impl.run(b, update=False)
+            torch.cuda.current_stream(self.net.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sloss = self.step_impl.run(b)
+            self._graph, self._static = g, (b["x"], b, sloss)
+            return
+        sx = torch.zeros(shape, dtype=self.net.dtype, device=self.net.device)
+        sy = torch.zeros_like(sx)
+        self.opt.keep_grads = True
         with torch.cuda.stream(side):                       # warm-up off the capture stream (allocator, lazy init)
             for _ in range(2):
                 loss = self.net.loss(sx, sy, self.keep_prob, None, self.engine)
@@ -294,20 +313,49 @@ class Trainer(object):
             self.opt.step()
         self._graph, self._static = g, (sx, sy, sloss)
 
-    def train_step(self, x, y, keep_prob=None):
+    def train_step(self, x, y, keep_prob=None, masks=None):
         kp = self.keep_prob if keep_prob is None else keep_prob
-        if self.use_graph and kp == self.keep_prob:
+        if self.use_graph and kp == self.keep_prob and masks is None:
             torch = __import__("torch")
             if self._graph is None or tuple(self._static[0].shape) != tuple(np.asarray(x).reshape(-1, 35).shape):
                 self._capture(x, y)          # first batch, or a new batch size: (re)capture the step
             sx, sy, sloss = self._static
-            sx.copy_(torch.as_tensor(np.asarray(x), dtype=self.net.dtype).reshape(sx.shape), non_blocking=True)
-            sy.copy_(torch.as_tensor(np.asarray(y), dtype=self.net.dtype).reshape(sy.shape), non_blocking=True)
+            if self.step_impl is not None:
+                self.step_impl.load_batch(sy, x, y)
+            else:
+                sx.copy_(torch.as_tensor(np.asarray(x), dtype=self.net.dtype).reshape(sx.shape), non_blocking=True)
+                sy.copy_(torch.as_tensor(np.asarray(y), dtype=self.net.dtype).reshape(sy.shape), non_blocking=True)
             self._graph.replay()
             self.last_loss = float(sloss.detach())
             return self.last_loss
-        loss = self.net.loss(x, y, kp, self.gen, self.engine)
+        if self.step_impl is not None:
+            n = int(np.asarray(x).reshape(-1, 35).shape[0])
+            if getattr(self, "_eager_bufs", None) is None or self._eager_bufs["n"] != n:
+                self._eager_bufs = self.step_impl._alloc(n)
+            self.step_impl.load_batch(self._eager_bufs, x, y)
+            self.last_loss = float(self.step_impl.run(self._eager_bufs, keep_prob=kp, masks=masks))
+            return self.last_loss
+        loss = self.net.loss(x, y, kp, self.gen, self.engine, masks)
         loss.backward()
         self.opt.step()
         self.last_loss = float(loss.detach())
         return self.last_loss
+
+    def gradients(self, x, y, keep_prob=None, masks=None):
+        """Loss and gradients of one batch WITHOUT an update: (loss, {TF name: ndarray}) -- what tests compare with the
+        reference graph's gradient tensors."""
+        kp = self.keep_prob if keep_prob is None else keep_prob
+        if self.step_impl is not None:
+            n = int(np.asarray(x).reshape(-1, 35).shape[0])
+            b = self.step_impl._alloc(n)
+            self.step_impl.load_batch(b, x, y)
+            loss = float(self.step_impl.run(b, keep_prob=kp, masks=masks, update=False))
+            return loss, {k: v.detach().cpu().numpy().copy() for k, v in self.step_impl.grads().items()}
+        for p in self.net.trainable().values():
+            p.grad = None
+        loss = self.net.loss(x, y, kp, self.gen, self.engine, masks)
+        loss.backward()
+        out = {k: p.grad.detach().cpu().numpy().copy() for k, p in self.net.trainable().items()}
+        for p in self.net.trainable().values():
+            p.grad = None
+        return float(loss.detach()), out

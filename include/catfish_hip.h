@@ -194,6 +194,21 @@ int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const flo
 int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
                           const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
                           int64_t n_windows, void* stream);
+/* The same two calls with the layer's OUTPUT dropout (DropoutWrapper(output_keep_prob), rnn_class.py:151-154) done inside the
+ * kernels, no mask tensor: whether an output element is kept is a hash of (seed, layer, *step_count, element index).  The
+ * forward additionally writes y_drop_frag = y * mask / keep_prob (what the next layer or the dense head reads; y_frag itself stays
+ * un-dropped for the recurrence and the backward pass); the backward applies the same factor to the incoming gradient when
+ * dy_scale is NULL and keep_prob < 1.  step_count: device double[1] (the optimizer's step counter, so every step draws a new mask
+ * even under graph replay) or NULL.  cf_dropout_scale writes that factor tensor out (tests / tools only). */
+int cf_gru_train_forward_dropout(cf_model* m, int32_t cin, const float* wpack, const float* x_frag, float* y_frag, float* stash,
+                                 int64_t n_windows, float* y_drop_frag, float keep_prob, uint32_t seed, int32_t layer,
+                                 const double* step_count, void* stream);
+int cf_gru_train_backward_dropout(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
+                                  const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
+                                  int64_t n_windows, float keep_prob, uint32_t seed, int32_t layer, const double* step_count,
+                                  void* stream);
+int cf_dropout_scale(cf_model* m, float keep_prob, uint32_t seed, int32_t layer, const double* step_count, int64_t n_windows,
+                     float* scale_frag, void* stream);
 /* dW of one biGRU layer from the fragment buffers (the weight-gradient half of optimizer.minimize(loss),
  * catfish/models/rnn_class.py:62-71): grads = per direction [ gates kernel [cin+64,128] | gates bias [128] |
  * candidate kernel [cin+64,64] | candidate bias [64] ] in TensorFlow layout, 2 directions back to back.
@@ -218,6 +233,26 @@ int cf_res_train_forward(cf_model* m, int32_t n_blocks, const float* params, con
 int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float* params, const float* x, const float* z_stash,
                           const float* d_out, float* workspace, int64_t workspace_floats, float* grads, int64_t n_windows,
                           void* stream);
+
+/* Dense head + loss of the training step, forward and backward in one pass (RNN.output_layer + RNN.compute_loss,
+ * catfish/models/rnn_class.py:178-183,74-79: final_fully_connected followed by tf.losses.sigmoid_cross_entropy, mean over
+ * all n_windows * 35 elements).  y_frag: the dense layer's input = last biGRU layer's output after output dropout, fragment
+ * layout [tiles][35][8][64][4]; labels: device fp32 [n_windows][35]; dense_kernel [128], dense_bias [1]: device pointers.
+ * Writes dy_frag (d loss / d y_frag, same layout), grads = d kernel [128] | d bias [1], loss[0] = the mean loss, and the
+ * logits [n_windows][35] when that pointer is not NULL.  workspace: cf_train_head_workspace_floats(m, n_windows) floats. */
+int64_t cf_train_head_workspace_floats(cf_model* m, int64_t n_windows);
+int cf_train_head(cf_model* m, const float* y_frag, const float* dense_kernel, const float* dense_bias, const float* labels,
+                  int64_t n_windows, float* dy_frag, float* logits, float* workspace, int64_t workspace_floats, float* grads,
+                  float* loss, void* stream);
+
+/* One optimizer step over ALL variables at once (optimizer.minimize(loss), rnn_class.py:62-71): params, grads and the two slot
+ * variables are flat device buffers of one layout, n floats each.  kind 0 = tf.train.RMSPropOptimizer(lr) (decay 0.9,
+ * momentum 0, epsilon 1e-10; slot1 = rms, initial value 1; slot2 = momentum), kind 1 = tf.train.AdamOptimizer(lr) (beta 0.9 /
+ * 0.999, epsilon 1e-8; slot1 = m, slot2 = v).  step_count: device double[1], steps taken so far; read by the update (Adam's bias
+ * correction) and incremented by this call.  When n_packed > 0 the updated weights are re-tiled for the biGRU kernels in the
+ * same call: packed[i] = params[pack_idx[i]] * pack_scale[i] (indices from cf_gru_pack_map, rebased into params). */
+int cf_opt_step(cf_model* m, int32_t kind, float* params, const float* grads, float* slot1, float* slot2, int64_t n, float lr,
+                double* step_count, const int32_t* pack_idx, const float* pack_scale, float* packed, int64_t n_packed, void* stream);
 
 /* Per-kernel device timing (HIP events on the launch stream) for bench.py's
  * roofline report.  cf_profile_enable(m, N) makes every N-th cf_infer call

@@ -467,6 +467,91 @@ def test_native_training_with_dropout_matches_the_reference_graph(ckpt_weights):
         eng.close()
 
 
+def test_train_head_kernel_matches_torch():
+    """cf_train_head (dense 128 -> 1 + sigmoid cross-entropy on the logits, forward and backward in one pass over the
+    fragment layout; rnn_class.py:178-183,74-79) against torch: loss, d kernel, d bias, d input, logits; a ragged batch
+    (padding windows must contribute nothing)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from catfish_amd import _native as N
+    from catfish_amd.engine import HipEngine
+    from catfish_amd.native_train import nat_to_frag, frag_to_nat
+    eng = HipEngine(oracle.random_weights(seed=1), device=0, max_windows_per_pass=256)
+    try:
+        for n in (256, 37, 3000):
+            g = torch.Generator(device="cpu").manual_seed(n)
+            npad = (n + 15) // 16 * 16
+            hin = (torch.rand(npad, 35, 128, generator=g) * 2 - 1).cuda()
+            w = (torch.randn(128, generator=g) * 0.3).cuda()
+            b = torch.tensor([0.17]).cuda()
+            y = (torch.rand(n, 35, generator=g) < 0.3).float().cuda()
+            yf = nat_to_frag(hin)
+            dy = torch.empty_like(yf)
+            logits = torch.zeros(n, 35, device="cuda")
+            ws = torch.empty(int(eng._lib.cf_train_head_workspace_floats(eng._handle, npad)), device="cuda")
+            grads = torch.zeros(129, device="cuda")
+            loss = torch.zeros(1, device="cuda")
+            p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+            N.check(eng._lib.cf_train_head(eng._handle, p(yf), p(w), p(b), p(y), n, p(dy), p(logits), p(ws), ws.numel(), p(grads), p(loss),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            href = hin[:n].clone().requires_grad_(True)
+            wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            z = href @ wr + br
+            lref = torch.nn.functional.binary_cross_entropy_with_logits(z, y, reduction="mean")
+            lref.backward()
+            assert abs(float(loss) - float(lref)) < 2e-6
+            assert torch.allclose(logits, z.detach(), atol=2e-5)
+            assert torch.allclose(grads[:128], wr.grad, atol=1e-6, rtol=1e-4) and abs(float(grads[128]) - float(br.grad)) < 1e-6
+            dnat = frag_to_nat(dy)
+            assert torch.allclose(dnat[:n], href.grad, atol=1e-9, rtol=1e-4)
+            assert float(dnat[n:].abs().max()) == 0.0 if npad > n else True
+    finally:
+        eng.close()
+
+
+def test_in_kernel_dropout_matches_torch_with_the_same_masks(ckpt_weights):
+    """The native training step draws its output-dropout masks INSIDE the biGRU kernels (a hash of seed, layer, optimizer
+    step and element index; no mask tensor).  cf_dropout_scale writes the same factors out; replayed through the
+    torch-autograd restatement of the graph they must give the same loss and gradients.  The masks keep ~keep_prob of
+    the elements, differ per layer and change with the optimizer step."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.training import Trainer, TorchResNetRNN
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1.2, size=(64, 35)).astype(np.float32)
+    y = np.repeat((np.arange(64) % 2)[:, None], 35, axis=1).astype(np.float32)
+    tr = Trainer(ckpt_weights, 3, 2, "RMSProp", 1e-3, keep_prob=0.8, device="cuda", native=True, seed=5, use_graph=False)
+    try:
+        masks = tr.step_impl.dropout_scales(64)
+        frac = np.mean([m.mean() for m in masks.values()])
+        assert abs(frac - 0.8) < 0.01
+        assert not np.array_equal(masks[(0, "fw")], masks[(1, "fw")]) and not np.array_equal(masks[(0, "fw")], masks[(0, "bw")])
+        loss_n, grads_n = tr.gradients(x, y)                               # in-kernel masks, no update
+        ref = TorchResNetRNN(ckpt_weights, 3, 2, device="cuda")
+        loss_r = ref.loss(x, y, keep_prob=0.8, masks=masks)
+        loss_r.backward()
+        assert abs(loss_n - float(loss_r.detach())) < 5e-6
+        for k, p in ref.trainable().items():
+            g_ref = p.grad.cpu().numpy()
+            assert np.abs(grads_n[k] - g_ref).max() <= 2e-3 * np.abs(g_ref).max() + 1e-9, k
+        # explicit masks replayed through the native step (the mask-tensor path) give the same result
+        loss_m, grads_m = tr.gradients(x, y, masks=masks)
+        assert abs(loss_m - loss_n) < 1e-6
+        assert all(np.allclose(grads_m[k], grads_n[k], rtol=1e-5, atol=1e-9) for k in grads_n)
+        # a training step advances the optimizer's step counter: new masks
+        tr.train_step(x, y)
+        masks2 = tr.step_impl.dropout_scales(64)
+        assert not np.array_equal(masks2[(0, "fw")], masks[(0, "fw")])
+        # the graph-captured step draws new masks on every replay as well (the kernels read the counter from device memory)
+        tg = Trainer(ckpt_weights, 3, 2, "RMSProp", 1e-3, keep_prob=0.8, device="cuda", native=True, seed=5, use_graph=True)
+        l1 = [tg.train_step(x, y) for _ in range(3)]
+        te = Trainer(ckpt_weights, 3, 2, "RMSProp", 1e-3, keep_prob=0.8, device="cuda", native=True, seed=5, use_graph=False)
+        l2 = [te.train_step(x, y) for _ in range(3)]
+        assert np.allclose(l1, l2, atol=1e-6), (l1, l2)                    # same seed: graph replay == eager, step by step
+        tg.engine.close(); te.engine.close()
+    finally:
+        tr.engine.close()
+
+
 def test_cli_end_to_end(tmp_path, ckpt_weights, monkeypatch):
     """`catfish -i IN -s OUT -c 300` (catfish/catfish:18-94): model directory with ResNetRNN.txt + a TF
     checkpoint-V2 bundle (written here from the exported tensors), a directory of reads, chunk coordinates out."""

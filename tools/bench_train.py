@@ -1,4 +1,4 @@
-"""BASELINE config 5: train step (forward + backward + Adam) on PyTorch-ROCm, windows/s.
+"""BASELINE config 5: train step (forward + backward + Adam), windows/s.
 
 Synthetic config-2 windows, per-window uniform labels, 128 positive + 128 negative per batch of
 256 (mimics ExampleDb.get_training_set, networks/trainingDB/ExampleDb.py:50-83), keep_prob 0.8,
@@ -59,7 +59,7 @@ def main():
                 t2.train_step(x, y)
             torch.cuda.synchronize()
             modes[name + "_ms_per_step"] = (time.perf_counter() - t1) / 5 * 1e3
-    print(json.dumps({"metric": "training windows/s (config 5: native HIP conv-stack and biGRU fwd/bwd/wgrad kernels; dense head, loss and optimizer in torch, TF-style Adam)",
+    print(json.dumps({"metric": "training windows/s (config 5: the whole step on HIP kernels through the C ABI -- conv stack, biGRU fwd/bwd/wgrad with in-kernel dropout, dense head + loss, fused TF-style Adam + re-tiling; no autograd)",
                       "device": dev, "native": bool(getattr(tr, "native", False)), "other_modes": modes,
                       "batch": B, "value": n * B / dt, "ms_per_step": dt / n * 1e3,
                       "loss_10_steps_device": lg, "loss_10_steps_cpu": lc,
