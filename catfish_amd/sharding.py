@@ -87,6 +87,48 @@ def host_gather_group():
     return dist.new_group(backend="gloo")
 
 
+class SpanTable(object):
+    """Results of many reads as four arrays instead of nested Python lists: what a rank hands to the host gather (numpy
+    arrays pickle at memcpy speed; a list of lists of ints does not).
+
+    read_of [n_spans]  position of the span's read in this table (ascending)
+    start, end [n_spans]  the reference's span coordinates (start - 11, end + 16; infer.py:141-162)
+    lengths [n_reads]  real length of every read
+    """
+
+    def __init__(self, read_of, start, end, lengths):
+        self.read_of = np.asarray(read_of, dtype=np.int64)
+        self.start = np.asarray(start, dtype=np.int64)
+        self.end = np.asarray(end, dtype=np.int64)
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+
+    def __len__(self):
+        return int(self.lengths.shape[0])
+
+    @classmethod
+    def from_lists(cls, results):
+        read_of = [i for i, (spans, _n) in enumerate(results) for _ in spans]
+        flat = [sp for spans, _n in results for sp in spans]
+        arr = np.asarray(flat, dtype=np.int64).reshape(-1, 2)
+        return cls(read_of, arr[:, 0], arr[:, 1], [n for _spans, n in results])
+
+    @classmethod
+    def concat(cls, tables):
+        if not tables:
+            return cls([], [], [], [])
+        offs = np.cumsum([0] + [len(t) for t in tables[:-1]])
+        return cls(np.concatenate([t.read_of + o for t, o in zip(tables, offs)]), np.concatenate([t.start for t in tables]),
+                   np.concatenate([t.end for t in tables]), np.concatenate([t.lengths for t in tables]))
+
+    def expand(self):
+        """-> [(spans, length)] per read, the reference's return values (one ``tolist`` + one slice per read)."""
+        n = len(self)
+        pairs = np.stack([self.start, self.end], axis=1).tolist()
+        bounds = np.concatenate(([0], np.cumsum(np.bincount(self.read_of, minlength=n)[:n]))).tolist()
+        lens = self.lengths.tolist()
+        return [(pairs[bounds[r]:bounds[r + 1]], lens[r]) for r in range(n)]
+
+
 def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group=None):
     """Shard ``len(costs)`` items by cost, run ``work_fn(list of my indices) -> list of results`` on this
     rank's shard, gather on rank 0.
@@ -103,24 +145,29 @@ def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group
     n_items = len(costs)
     shards = shard_costs(costs, world_size)
     mine = shards[rank]
-    local = list(work_fn(mine)) if mine else []
+    local = work_fn(mine) if mine else []
+    if not isinstance(local, SpanTable):
+        local = list(local)
     if len(local) != len(mine):
         raise RuntimeError("work_fn returned %d results for %d items" % (len(local), len(mine)))
+
+    def place(out, idx, res):
+        for i, r in zip(idx, res.expand() if isinstance(res, SpanTable) else res):
+            out[i] = r
+
     if world_size == 1:
         out = [None] * n_items
-        for i, res in zip(mine, local):
-            out[i] = res
+        place(out, mine, local)
         return out
     if not distributed:
         raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group")
     gathered = [None] * world_size if rank == 0 else None
-    dist.gather_object(list(zip(mine, local)), gathered, dst=0, group=gather_group)
+    dist.gather_object((mine, local), gathered, dst=0, group=gather_group)     # a SpanTable travels as four arrays
     if rank != 0:
         return None
     out = [None] * n_items
-    for part in gathered:
-        for i, res in part:
-            out[i] = res
+    for idx, res in gathered:
+        place(out, idx, res)
     return out
 
 
@@ -167,8 +214,10 @@ class EngineBatchRunner(object):
         self.threshold, self.min_run = threshold, min_run
         self.pipe = ReadPipeline(self.engine, self.max_samples, threshold=threshold, min_run=min_run)
 
-    def run(self, batches):
-        """``batches``: iterable of lists of raw reads -> yields [(spans, length)] per batch, in order."""
+    def run(self, batches, compact=False):
+        """``batches``: iterable of lists of raw reads -> yields per batch, in order, ``[(spans, length)]`` or (``compact``)
+        a ``SpanTable`` of the batch."""
+        self.compact = bool(compact)
         from . import batching
         from .infer import is_dac, normalize_raw_signal
         pending = None           # (ticket, host-path results or None)
@@ -188,7 +237,12 @@ class EngineBatchRunner(object):
 
     def _finish(self, item):
         ticket, host_res = item
-        return self.pipe.collect(ticket) if ticket is not None else host_res
+        if ticket is None:
+            return SpanTable.from_lists(host_res) if self.compact else host_res
+        if not self.compact:
+            return self.pipe.collect(ticket)
+        read_of, start, end, lengths = self.pipe.collect(ticket, as_lists=False)
+        return SpanTable(read_of, start, end, lengths)
 
 
 def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_per_batch=None, batch_runner=None,
@@ -234,6 +288,8 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
                     tot += len(r)
                 if cur:
                     yield cur
+        if isinstance(runner, EngineBatchRunner):          # arrays all the way to the gather; lists are built once, on rank 0
+            return SpanTable.concat(list(runner.run(batches(), compact=True)))
         out = []
         for res in runner.run(batches()):
             out.extend(res)

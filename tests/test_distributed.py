@@ -135,6 +135,26 @@ def test_two_rank_sharded_runner_with_fake_engine(tmp_path):
     assert (tmp_path / "ok2").exists()
 
 
+def test_span_table_round_trips_the_reference_result_lists():
+    """What a rank sends through the host gather: four arrays that expand to exactly the reference's per-read
+    ``(spans, length)`` (infer.py:12-51), empty reads and empty shards included."""
+    sys.path.insert(0, ROOT)
+    from catfish_amd.sharding import SpanTable
+    rng = np.random.default_rng(0)
+    res = []
+    for _ in range(200):
+        k = int(rng.integers(0, 6))
+        starts = np.sort(rng.integers(-11, 4000, size=k))
+        res.append(([[int(s), int(s) + 42] for s in starts], int(rng.integers(1, 5000))))
+    t = SpanTable.from_lists(res)
+    assert len(t) == 200 and t.expand() == res
+    parts = [SpanTable.from_lists(res[:50]), SpanTable.from_lists([]), SpanTable.from_lists(res[50:51]), SpanTable.from_lists(res[51:])]
+    assert SpanTable.concat(parts).expand() == res
+    assert SpanTable.concat([]).expand() == [] and SpanTable.from_lists([([], 7)]).expand() == [([], 7)]
+    import pickle
+    assert len(pickle.dumps(t)) < len(pickle.dumps(res))
+
+
 def test_shard_costs_balances_and_covers():
     sys.path.insert(0, ROOT)
     from catfish_amd import sharding
