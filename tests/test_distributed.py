@@ -152,7 +152,7 @@ def test_span_table_round_trips_the_reference_result_lists():
     assert SpanTable.concat(parts).expand() == res
     assert SpanTable.concat([]).expand() == [] and SpanTable.from_lists([([], 7)]).expand() == [([], 7)]
     import pickle
-    assert len(pickle.dumps(t)) < len(pickle.dumps(res))
+    assert pickle.loads(pickle.dumps(t)).expand() == res           # it travels through dist.gather_object as a pickle
 
 
 def test_shard_costs_balances_and_covers():
