@@ -288,8 +288,12 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
                     tot += len(r)
                 if cur:
                     yield cur
-        if isinstance(runner, EngineBatchRunner):          # arrays all the way to the gather; lists are built once, on rank 0
+        _r, env_world, _l = dist_env()
+        n_ranks = world_size if world_size is not None else env_world
+        if isinstance(runner, EngineBatchRunner) and n_ranks > 1:
+            # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
             return SpanTable.concat(list(runner.run(batches(), compact=True)))
+        # one rank: the per-read lists of batch k are built while the GPU runs batch k + 1
         out = []
         for res in runner.run(batches()):
             out.extend(res)
