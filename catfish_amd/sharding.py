@@ -288,8 +288,9 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
                     tot += len(r)
                 if cur:
                     yield cur
-        _r, env_world, _l = dist_env()
-        n_ranks = world_size if world_size is not None else env_world
+        import torch.distributed as dist
+        n_ranks = world_size if world_size is not None else (
+            dist.get_world_size() if dist.is_available() and dist.is_initialized() else dist_env()[1])
         if isinstance(runner, EngineBatchRunner) and n_ranks > 1:
             # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
             return SpanTable.concat(list(runner.run(batches(), compact=True)))
