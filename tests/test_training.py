@@ -106,3 +106,21 @@ def test_trainer_has_no_silent_cpu_fallback():
     w = oracle.random_weights(seed=1, n_layers=1, n_layers_res=1)
     with pytest.raises(RuntimeError, match="no HIP device"):
         Trainer(w, 1, 1, "Adam", 1e-3, keep_prob=1.0)
+
+
+def test_adam_step_count_survives_a_long_run():
+    """tf.train.Saver stores beta1_power = 0.9^(t+1) and beta2_power = 0.999^(t+1) as float32.  After ~830 steps the first
+    is denormal / zero, so the step count is restored from the second (and a huge count stands in when that is gone
+    too: the bias corrections are 1 by then)."""
+    p = {"w": torch.tensor([1.0, -2.0], dtype=torch.float32, requires_grad=True)}
+    for t in (0, 5, 500, 3000, 50000):
+        opt = TFOptimizer(p, "Adam", 0.1)
+        opt.t.fill_(t)
+        state = opt.state_tf()
+        assert state["optimizer/beta1_power"].dtype == np.float32
+        fresh = TFOptimizer(p, "Adam", 0.1)
+        fresh.load_state_tf(state)
+        assert abs(float(fresh.t) - t) <= max(1, t * 1e-3), (t, float(fresh.t))
+    gone = TFOptimizer(p, "Adam", 0.1)
+    gone.load_state_tf({"optimizer/beta1_power": np.float32(0.0), "optimizer/beta2_power": np.float32(0.0)})
+    assert float(gone.t) >= 1e5
