@@ -281,12 +281,16 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
 // block 0 in the same stream, so block 0's 32-channel output goes from its accumulators straight into block 1's
 // first MFMAs (the accumulator layout is a B-operand layout, see the header) and never exists in HBM: 256 B per
 // sample of traffic and one launch less.  Same operations in the same order as two res_block_kernel launches:
-// bit-identical output.
+// bit-identical output.  Small calls (latency mode) split a tile's 35 positions into `t_chunks` chunks, one wave each, on
+// as many CUs as the call leaves idle: a chunk starts two positions early (block 0's k=3 neighbourhood, then block 1's),
+// so a single read's conv stack is ~7 positions deep instead of 2 x 35; there block 0's output is also stored (y0_frag)
+// for the debug / test hook.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict__ wpack0, const float* __restrict__ wpack1,
                                                          const float* __restrict__ x_nat,   // [n_windows, 35]
                                                          f32x4* __restrict__ y_frag,        // [tile][t][2][lane], block 1's output
-                                                         int64_t n_windows, int n_tiles) {
+                                                         f32x4* __restrict__ y0_frag,       // block 0's output, or null
+                                                         int64_t n_windows, int n_tiles, int t_chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PACK0 = res_pack_floats(true), PACK1 = res_pack_floats(false);
     constexpr int VEC0 = res_units(true) * 1024, VEC1 = res_units(false) * 1024;
@@ -309,7 +313,12 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
     auto vec1 = [&](int v, int mo) -> f32x4 { return *reinterpret_cast<const f32x4*>(w1 + VEC1 + v * 32 + mo * 16 + q * 4); };
     const f32x4 zero = {0, 0, 0, 0};
 
-    for (int tile = blockIdx.x * waves_per_block + wave; tile < n_tiles; tile += gridDim.x * waves_per_block) {
+    const int chunk_len = (CF_T + t_chunks - 1) / t_chunks;
+    for (int task = blockIdx.x * waves_per_block + wave; task < n_tiles * t_chunks; task += gridDim.x * waves_per_block) {
+        const int tile = task / t_chunks;
+        const int p0 = (task - tile * t_chunks) * chunk_len;          // this wave writes positions [p0, p1)
+        const int p1 = min(p0 + chunk_len, CF_T);
+        if (p0 >= p1) continue;
         {
             const int64_t base = (int64_t)tile * CF_TILE * CF_T;
             const int64_t limit = n_windows * CF_T;
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
         for (int mo = 0; mo < 2; ++mo) { w_sc[mo] = vec0(2, mo); b_sc[mo] = vec0(3, mo); w_f[mo] = vec0(4, mo); b_f[mo] = vec0(5, mo); }
         f32x4 a_pp[2] = {zero, zero}, a_p[2] = {zero, zero}, a_sp[2] = {zero, zero};     // block 0: o1[t-1], o1[t], shortcut[t]
         f32x4 b_pp[2] = {zero, zero}, b_p[2] = {zero, zero}, b_sp[2] = {zero, zero};     // block 1, one position behind
-        for (int i = 0; i <= CF_T + 1; ++i) {
+        for (int i = p0 > 2 ? p0 - 2 : 0; i <= p1 + 1; ++i) {
             // ---- block 0, front at position i: Cin = 1, conv1d is a rank-1 update (resnet_class.py:60,64)
             f32x4 a_c[2] = {zero, zero}, a_sc[2] = {zero, zero};
             if (i < CF_T) {
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
             }
             // ---- block 0, back: its output at position i - 1 stays in registers as block 1's input
             f32x4 y0[2] = {zero, zero};
-            const bool have_y0 = i >= 1 && i <= CF_T;
+            const bool have_y0 = i >= 1 && i <= CF_T && i >= p0;       // block 0's output at i - 1 >= p0 - 1
             if (have_y0) {
                 f32x4 acc[2] = {vec0(0, 0), vec0(0, 1)};
                 unit_mma(w0 + 0 * 1024, lane, a_pp, acc);                 // tap 0 * o1[t-1]
@@ -347,6 +356,11 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
                 unit_mma(w0 + 3 * 1024, lane, o2, acc3);                  // last conv (:74-76)
                 y0[0] = relu4(relu4(acc3[0]) + a_sp[0]);                  // add + relu (:79-80)
                 y0[1] = relu4(relu4(acc3[1]) + a_sp[1]);
+                if (y0_frag && i - 1 >= p0 && i - 1 < p1) {
+                    f32x4* d0 = y0_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
+                    d0[0] = y0[0];
+                    d0[64] = y0[1];
+                }
             }
             // ---- block 1, front at position p = i - 1 (zero padding past the window end, p = T)
             f32x4 b_c[2] = {zero, zero}, b_sc[2] = {zero, zero};
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
                 b_c[0] = relu4(acc[0]); b_c[1] = relu4(acc[1]);
             }
             // ---- block 1, back: output position p - 1 = i - 2
-            if (i >= 2) {
+            if (i >= 2 && i - 2 >= p0 && i - 2 < p1) {
                 f32x4 acc[2] = {vec1(2, 0), vec1(2, 1)};
                 unit_mma(w1 + 2 * 1024, lane, b_pp, acc);
                 unit_mma(w1 + 3 * 1024, lane, b_p, acc);
@@ -713,7 +727,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x_
 // transposing the [tile][t][16] partials back to the reference's window-major order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, float bias, float* __restrict__ probs,
-                                                   float* __restrict__ logits, int64_t n_windows, int n_tiles, int tile_shift) {
+                                                   float* __restrict__ logits, int64_t n_windows, int n_tiles, int tile_shift, int raw) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_windows * CF_T) return;
     const int64_t w = idx / CF_T;
@@ -721,7 +735,23 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ P, 
     const int64_t tile = w >> tile_shift;            // 16-window tiles (fp32 path) or 32-window tiles (bf16 path)
     const int tw = 1 << tile_shift;
     const int wl = (int)(w & (tw - 1));
-    const float z = P[((tile)*CF_T + t) * tw + wl] + P[(((int64_t)n_tiles + tile) * CF_T + t) * tw + wl] + bias;
+    float z;
+    if (raw) {
+        // latency-mode kernels leave per-lane partials [dir][tile][t][4 M-tiles][64 lanes]: M-tile sums added in order, then
+        // the lane quarters as the one-wave kernel's two xor-shuffles do: (q0 + q1) + (q2 + q3)
+        float pd[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const float* src = P + ((((int64_t)d * n_tiles + tile) * CF_T + t) * 4) * 64 + wl;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ((src[q * 16] + src[64 + q * 16]) + src[128 + q * 16]) + src[192 + q * 16];
+            pd[d] = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        z = pd[0] + pd[1] + bias;
+    } else {
+        z = P[((tile)*CF_T + t) * tw + wl] + P[(((int64_t)n_tiles + tile) * CF_T + t) * tw + wl] + bias;
+    }
     if (logits) logits[idx] = z;
     if (probs) probs[idx] = 1.0f / (1.0f + expf(-z));
 }
@@ -1187,7 +1217,9 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         m->cap_tiles = cap / CF_TILE;
         const size_t a_bytes = (size_t)m->cap_tiles * CF_T * 2 * 64 * sizeof(f32x4);
         const size_t y_bytes = (size_t)m->cap_tiles * CF_T * 8 * 64 * sizeof(f32x4);
-        const size_t p_bytes = (size_t)2 * m->cap_tiles * CF_T * 16 * sizeof(float);
+        // dense partials: [2][tiles][35][16] from the throughput kernels, [2][tiles <= CUs][35][4][64] per-lane partials from the
+        // latency-mode kernels
+        const size_t p_bytes = std::max((size_t)2 * m->cap_tiles * CF_T * 16, (size_t)2 * std::min<int64_t>(m->cap_tiles, m->n_cu) * CF_T * 256) * sizeof(float);
         hipError_t e = hipSuccess;
         int n_slots = hp->n_streams > 0 ? hp->n_streams : 1;   // measured: splitting one call over 2 internal streams is slower
         if (n_slots > 8) n_slots = 8;
@@ -1291,12 +1323,16 @@ static int pick_waves(int n_tile_tasks, int n_cu) {
     return w <= 1 ? 1 : (w <= 2 ? 2 : (w <= 4 ? 4 : 8));
 }
 
+// latency mode: up to two rounds of one (tile, direction) per CU (0.35 units each) beat one wave per tile (1 unit)
+static bool use_coop(const cf_model* m, int n_tiles) {
+    static const int coop_env = getenv("CATFISH_COOP") ? atoi(getenv("CATFISH_COOP")) : -1;      // A/B knob for tools/
+    const bool coop = coop_env >= 0 ? coop_env != 0 : n_tiles <= m->n_cu;
+    return coop && !(CF_ABLATE & 4) && n_tiles <= m->n_cu;      // (the raw dense-partial buffer is sized for n_cu tiles)
+}
+
 template <int CIN, bool LAST>
 static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
-    static const int coop_env = getenv("CATFISH_COOP") ? atoi(getenv("CATFISH_COOP")) : -1;      // A/B knob for tools/
-    // latency mode: up to two rounds of one (tile, direction) per CU (0.35 units each) beat one wave per tile (1 unit)
-    const bool coop = coop_env >= 0 ? coop_env != 0 : n_tiles <= m->n_cu;
-    if (coop && !(CF_ABLATE & 4)) {
+    if (use_coop(m, n_tiles)) {
         size_t pi = 0;
         int rc = prof_begin(m, slot, s, &pi);
         if (rc != CF_OK) return rc;
@@ -1381,14 +1417,23 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     const int res_grid = res_split ? n_tiles : std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
     // throughput mode (fp32): the first two blocks as ONE launch, block 0's output stays in registers
     static const int res_fuse_env = getenv("CATFISH_RES_FUSE") ? atoi(getenv("CATFISH_RES_FUSE")) : 1;   // A/B knob for tools/
-    const bool res_fused = m->np == 0 && !res_split && m->hp.n_layers_res >= 2 && res_fuse_env != 0;
-    sl.last_res_fused = res_fused;
+    const bool res_fused = m->np == 0 && m->hp.n_layers_res >= 2 && res_fuse_env != 0;
+    sl.last_res_fused = res_fused && !res_split;       // (latency mode also stores block 0's output, for the debug hook)
     if (res_fused) {
         if ((rc = prof_begin(m, SLOT_RES_STACK2, s, &pi)) != CF_OK) return rc;
-        const int lds_bytes = (res_pack_floats(true) + res_pack_floats(false) + res_waves * CF_TILE * CF_T) * 4;
-        const int grid2 = std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 3);     // 51 KB of LDS: three workgroups per CU
-        hipLaunchKernelGGL(res_stack2_kernel, dim3(grid2), dim3(res_waves * 64), lds_bytes, s, m->d_res[0], m->d_res[1], x,
-                           reinterpret_cast<f32x4*>(sl.d_a[1]), n_windows, n_tiles);
+        // latency mode: chunks of positions, one wave each, spread over the idle CUs (about four waves per CU in all)
+        int chunks = 1;
+        if (res_split) {
+            const int want = std::max(4, std::min(CF_T, (4 * m->n_cu) / std::max(1, n_tiles)));
+            const int len = (CF_T + want - 1) / want;
+            chunks = (CF_T + len - 1) / len;
+        }
+        const int waves2 = res_split ? 4 : res_waves;
+        const int lds_bytes = (res_pack_floats(true) + res_pack_floats(false) + waves2 * CF_TILE * CF_T) * 4;
+        const int grid2 = std::min((n_tiles * chunks + waves2 - 1) / waves2, m->n_cu * 3);     // 51 KB of LDS: three workgroups per CU
+        hipLaunchKernelGGL(res_stack2_kernel, dim3(grid2), dim3(waves2 * 64), lds_bytes, s, m->d_res[0], m->d_res[1], x,
+                           reinterpret_cast<f32x4*>(sl.d_a[1]), res_split ? reinterpret_cast<f32x4*>(sl.d_a[0]) : (f32x4*)nullptr,
+                           n_windows, n_tiles, chunks);
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     }
@@ -1485,8 +1530,9 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     // head
     if ((rc = prof_begin(m, SLOT_HEAD, s, &pi)) != CF_OK) return rc;
     const int64_t total = n_windows * CF_T;
+    const int raw_partials = (m->np == 0 && !fuse_now && use_coop(m, n_tiles)) ? 1 : 0;     // what the last biGRU launch left in d_p
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sl.d_p, m->dense_bias, probs, logits, n_windows,
-                       m->np > 0 ? n_tiles32 : n_tiles, m->np > 0 ? 5 : 4);
+                       m->np > 0 ? n_tiles32 : n_tiles, m->np > 0 ? 5 : 4, raw_partials);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     sl.last_windows = n_windows;

@@ -40,7 +40,6 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;
     f32x4* hx = reinterpret_cast<f32x4*>(xch) + lane;              // [4 M-tiles][64 lanes] f32x4: the state h
     f32x4* rx = hx + 4 * 64;                                        // r * h
-    float* pl = xch + 2 * 4 * 64 * 4;                               // [4 waves][64 lanes] dense partial sums (LAST)
 
     hx[W * 64] = (f32x4){0, 0, 0, 0};                               // GRUCellZeroState (every wave zeroes its own tile)
     __syncthreads();
@@ -153,19 +152,15 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
                 }
             }
         } else {
+            // partial logit of this wave's 16 hidden units, per lane, straight to global memory: head_kernel adds the four
+            // M-tile sums and the lane quarters in the one-wave kernel's order (bit-identical), so the recurrence carries
+            // neither an LDS round trip nor a serial reduction by one wave
             const f32x4 wd = *(reinterpret_cast<const f32x4*>(lds + DENSE) + q + W * 4);
             float p = wd.x * hown.x;
             p = fmaf(wd.y, hown.y, p); p = fmaf(wd.z, hown.z, p); p = fmaf(wd.w, hown.w, p);
-            pl[W * 64 + lane] = p;                                  // this M-tile's chain, per lane
+            P[((((int64_t)dir * n_tiles + tile) * CF_T + t) * 4 + W) * 64 + lane] = p;
         }
         __syncthreads();
-        if constexpr (LAST && W == 0) {
-            // the one-wave kernel's order: M-tile sums added in order, then the lane quarters
-            float p = ((pl[lane] + pl[64 + lane]) + pl[128 + lane]) + pl[192 + lane];
-            p += __shfl_xor(p, 16);
-            p += __shfl_xor(p, 32);
-            if (lane < 16) P[(((int64_t)dir * n_tiles + tile) * CF_T + t) * 16 + lane] = p;
-        }
     }
 }
 
