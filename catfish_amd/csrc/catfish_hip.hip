@@ -1367,11 +1367,14 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
 
 template <int CIN, bool LAST, int NP>
 static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float* Y, float* P, int n_tiles32, hipStream_t s, int slot) {
-    const int waves = pick_waves(2 * n_tiles32, m->n_cu);
+    static const int waves_env = getenv("CATFISH_BF16_WAVES") ? atoi(getenv("CATFISH_BF16_WAVES")) : 0;     // A/B knobs for tools/
+    static const int wgs_env = getenv("CATFISH_BF16_WGS") ? atoi(getenv("CATFISH_BF16_WGS")) : 0;
+    const int waves = waves_env > 0 ? std::min(waves_env, 8) : pick_waves(2 * n_tiles32, m->n_cu);
     const int groups = (n_tiles32 + waves - 1) / waves;           // one workgroup pass = one 32-window tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;
     constexpr int lds_bytes = gb_pack_bytes(CIN, NP);
     if (lds_bytes <= 80 * 1024) per_dir *= 2;
+    if (wgs_env > 0) per_dir = wgs_env;
     const int gx = groups < per_dir ? groups : per_dir;
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
