@@ -632,8 +632,8 @@ def test_sharded_runner_world1_real_engine(model, ckpt_weights, tmp_path):
 
 @pytest.mark.timeout(600)
 def test_cli_two_ranks_share_one_gpu(tmp_path, ckpt_weights):
-    """The multi-GPU entry point end to end: `torch.distributed.run --nproc-per-node 2 -m catfish_amd.cli` (what
-    `catfish --gpus 2` starts), both ranks pinned to cuda:0 by CATFISH_DEVICE because this box has one GPU.
+    """The multi-GPU entry point end to end: `catfish --gpus 2`, which starts `torch.distributed.run --nproc-per-node 2
+    -m catfish_amd.cli` as a child process; both ranks pinned to cuda:0 by CATFISH_DEVICE because this box has one GPU.
     Rank 0 gathers over gloo and writes the chunk coordinates; they must equal the per-read oracle."""
     import json
     import subprocess
@@ -650,8 +650,9 @@ def test_cli_two_ranks_share_one_gpu(tmp_path, ckpt_weights):
         dacs["read%d.npy" % i] = d
     env = dict(os.environ, CATFISH_DEVICE="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", "-m", "catfish_amd.cli", "-i", str(reads), "-s", str(tmp_path / "out"), "-c", "300"]
+    # `catfish --gpus 2`: the CLI starts torch.distributed.run (--nproc-per-node 2 -m catfish_amd.cli ...) as a child process
+    env["MASTER_PORT"] = "29533"
+    cmd = [sys.executable, "-m", "catfish_amd.cli", "-i", str(reads), "-s", str(tmp_path / "out"), "-c", "300", "--gpus", "2"]
     res = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          universal_newlines=True, timeout=500)
     assert res.returncode == 0, res.stdout[-3000:]
