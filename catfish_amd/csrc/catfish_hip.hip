@@ -1980,8 +1980,9 @@ extern "C" int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float*
 
 // ---- dense head + loss, optimizer (training) ------------------------------------------------
 static int head_waves(const cf_model* m, int64_t n_windows) {
+    // a wave takes ~8 (tile, t) items: few enough partial sums that the fixed-order reduction stays a couple of microseconds
     const int64_t items = ((n_windows + CF_TILE - 1) / CF_TILE) * CF_T;
-    const int64_t wgs = std::min<int64_t>((items + 3) / 4, (int64_t)m->n_cu * 2);
+    const int64_t wgs = std::min<int64_t>((items + 31) / 32, (int64_t)m->n_cu * 2);
     return (int)std::max<int64_t>(1, wgs) * 4;
 }
 
