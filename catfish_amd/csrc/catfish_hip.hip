@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void res_block_kernel(const float* __restrict_
 // so a single read's conv stack is ~7 positions deep instead of 2 x 35; there block 0's output is also stored (y0_frag)
 // for the debug / test hook.
 // ------------------------------------------------------------------------------------------
+template <bool CHUNKED>
 __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict__ wpack0, const float* __restrict__ wpack1,
                                                          const float* __restrict__ x_nat,   // [n_windows, 35]
                                                          f32x4* __restrict__ y_frag,        // [tile][t][2][lane], block 1's output
@@ -313,12 +314,13 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
     auto vec1 = [&](int v, int mo) -> f32x4 { return *reinterpret_cast<const f32x4*>(w1 + VEC1 + v * 32 + mo * 16 + q * 4); };
     const f32x4 zero = {0, 0, 0, 0};
 
-    const int chunk_len = (CF_T + t_chunks - 1) / t_chunks;
+    if (!CHUNKED) t_chunks = 1;                                       // throughput mode: the chunk arithmetic folds away
+    const int chunk_len = CHUNKED ? (CF_T + t_chunks - 1) / t_chunks : CF_T;
     for (int task = blockIdx.x * waves_per_block + wave; task < n_tiles * t_chunks; task += gridDim.x * waves_per_block) {
-        const int tile = task / t_chunks;
-        const int p0 = (task - tile * t_chunks) * chunk_len;          // this wave writes positions [p0, p1)
-        const int p1 = min(p0 + chunk_len, CF_T);
-        if (p0 >= p1) continue;
+        const int tile = CHUNKED ? task / t_chunks : task;
+        const int p0 = CHUNKED ? (task - tile * t_chunks) * chunk_len : 0;      // this wave writes positions [p0, p1)
+        const int p1 = CHUNKED ? min(p0 + chunk_len, CF_T) : CF_T;
+        if (CHUNKED && p0 >= p1) continue;
         {
             const int64_t base = (int64_t)tile * CF_TILE * CF_T;
             const int64_t limit = n_windows * CF_T;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void res_stack2_kernel(const float* __restrict
                 unit_mma(w0 + 3 * 1024, lane, o2, acc3);                  // last conv (:74-76)
                 y0[0] = relu4(relu4(acc3[0]) + a_sp[0]);                  // add + relu (:79-80)
                 y0[1] = relu4(relu4(acc3[1]) + a_sp[1]);
-                if (y0_frag && i - 1 >= p0 && i - 1 < p1) {
+                if (CHUNKED && y0_frag && i - 1 >= p0 && i - 1 < p1) {
                     f32x4* d0 = y0_frag + ((int64_t)tile * CF_T + (i - 1)) * 2 * 64 + lane;
                     d0[0] = y0[0];
                     d0[64] = y0[1];
@@ -1273,7 +1275,8 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_train_fwd_kernel<128>, gru_pack_floats(128) * 4);
         optin((const void*)gru_train_bwd_kernel<32>, gtb_pack_floats(32) * 4);
         optin((const void*)gru_train_bwd_kernel<128>, gtb_pack_floats(128) * 4);
-        optin((const void*)res_stack2_kernel, (res_pack_floats(true) + res_pack_floats(false) + 4 * CF_TILE * CF_T) * 4);
+        optin((const void*)res_stack2_kernel<true>, (res_pack_floats(true) + res_pack_floats(false) + 4 * CF_TILE * CF_T) * 4);
+        optin((const void*)res_stack2_kernel<false>, (res_pack_floats(true) + res_pack_floats(false) + 4 * CF_TILE * CF_T) * 4);
         optin((const void*)res_train_fwd_kernel, RT_FWD_LDS_BYTES);
         optin((const void*)res_train_bwd_kernel, RT_BWD_LDS_BYTES);
         optin((const void*)gru_layer_bf16_kernel<32, false, 1>, gb_pack_bytes(32, 1));
@@ -1434,9 +1437,12 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         const int waves2 = res_split ? 4 : res_waves;
         const int lds_bytes = (res_pack_floats(true) + res_pack_floats(false) + waves2 * CF_TILE * CF_T) * 4;
         const int grid2 = std::min((n_tiles * chunks + waves2 - 1) / waves2, m->n_cu * 3);     // 51 KB of LDS: three workgroups per CU
-        hipLaunchKernelGGL(res_stack2_kernel, dim3(grid2), dim3(waves2 * 64), lds_bytes, s, m->d_res[0], m->d_res[1], x,
-                           reinterpret_cast<f32x4*>(sl.d_a[1]), res_split ? reinterpret_cast<f32x4*>(sl.d_a[0]) : (f32x4*)nullptr,
-                           n_windows, n_tiles, chunks);
+        if (res_split)
+            hipLaunchKernelGGL(res_stack2_kernel<true>, dim3(grid2), dim3(waves2 * 64), lds_bytes, s, m->d_res[0], m->d_res[1], x,
+                               reinterpret_cast<f32x4*>(sl.d_a[1]), reinterpret_cast<f32x4*>(sl.d_a[0]), n_windows, n_tiles, chunks);
+        else
+            hipLaunchKernelGGL(res_stack2_kernel<false>, dim3(grid2), dim3(waves2 * 64), lds_bytes, s, m->d_res[0], m->d_res[1], x,
+                               reinterpret_cast<f32x4*>(sl.d_a[1]), (f32x4*)nullptr, n_windows, n_tiles, 1);
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     }
