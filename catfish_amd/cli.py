@@ -114,11 +114,13 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
                                                gather_group=sharding.host_gather_group())
         if rank != 0:
             return None, None
-        for fast5_file, (hp_positions, len_read) in zip(input_files, results):
-            merged_positions, nonhp = chunks_of_read(hp_positions, len_read, chunk_size)
-            if merged_positions is not None:
-                hp_dict[fast5_file] = merged_positions
-            nonhp_dict[fast5_file] = nonhp
+        from .batching import quiet_gc
+        with quiet_gc():                      # the merge loop creates as many small lists again
+            for fast5_file, (hp_positions, len_read) in zip(input_files, results):
+                merged_positions, nonhp = chunks_of_read(hp_positions, len_read, chunk_size)
+                if merged_positions is not None:
+                    hp_dict[fast5_file] = merged_positions
+                nonhp_dict[fast5_file] = nonhp
         print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
 
         print("Splitting reads...")

@@ -41,6 +41,7 @@ class ReadPipeline(object):
         # two pinned staging buffers (double buffering)
         self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(2)]
         self.stage_free = [torch.cuda.Event() for _ in range(2)]
+        self.tab = [None, None]                                  # pinned offset / length tables per staging slot
         self.k = 0
 
     def submit(self, dac_reads):
@@ -69,12 +70,22 @@ class ReadPipeline(object):
         host = self.stage[slot].numpy()
         for r, o in zip(dac_reads, dac_off[:-1]):
             host[o:o + len(r)] = r
+        # the four small tables go up from PINNED memory too, as one copy: a pageable source makes the runtime pin user
+        # pages for the transfer, and host allocator activity (munmap) near such mappings stalls the GPU queues
+        n_r = len(dac_reads)
+        n_tab = 4 * (n_r + 1)
+        if self.tab[slot] is None or self.tab[slot].numel() < n_tab:
+            self.tab[slot] = torch.empty(max(n_tab, 1024), dtype=torch.int64, pin_memory=True)
+        tab = self.tab[slot].numpy()
+        tab[0:n_r + 1] = dac_off
+        tab[n_r + 1:2 * n_r + 2] = win_off
+        tab[2 * n_r + 2:3 * n_r + 3] = win_off * WINDOW_SIZE
+        tab[3 * n_r + 3:4 * n_r + 3] = lengths
         with torch.cuda.stream(self.copy):
             d_dac = self.stage[slot][:total].to(self.dev, non_blocking=True)
-            d_doff = torch.from_numpy(dac_off).to(self.dev, non_blocking=True)
-            d_woff = torch.from_numpy(win_off).to(self.dev, non_blocking=True)
-            d_soff = torch.from_numpy(win_off * WINDOW_SIZE).to(self.dev, non_blocking=True)
-            d_len = torch.from_numpy(lengths).to(self.dev, non_blocking=True)
+            d_tab = self.tab[slot][:n_tab].to(self.dev, non_blocking=True)
+            d_doff, d_woff = d_tab[0:n_r + 1], d_tab[n_r + 1:2 * n_r + 2]
+            d_soff, d_len = d_tab[2 * n_r + 2:3 * n_r + 3], d_tab[3 * n_r + 3:4 * n_r + 3]
             self.stage_free[slot].record(self.copy)
             # normalisation rides on the copy stream: it overlaps the previous batch's biGRU kernels (which leave
             # wave slots and 15 KiB of LDS free on every CU) instead of delaying this batch's
@@ -112,7 +123,7 @@ class ReadPipeline(object):
             t.done = torch.cuda.Event()
             t.done.record(self.down)
         t.lengths, t.s_off, t.max_runs, t.labels = lengths, win_off * WINDOW_SIZE, max_runs, labels
-        t.keep = (d_dac, d_doff, d_woff, d_soff, d_len, x, probs, slot)   # keep device buffers alive until collected
+        t.keep = (d_dac, d_tab, x, probs, slot)                  # keep device buffers alive until collected
         self.inflight[slot] = t
         return t
 
@@ -140,11 +151,13 @@ class ReadPipeline(object):
 
     def run(self, batches, as_lists=True):
         """Iterate over batches (lists of int16 reads) with one batch in flight ahead; yields results."""
+        from .batching import quiet_gc
         pending = None
-        for b in batches:
-            ticket = self.submit(b)
+        with quiet_gc():                      # list building must not trigger collections that walk the whole process
+            for b in batches:
+                ticket = self.submit(b)
+                if pending is not None:
+                    yield self.collect(pending, as_lists)
+                pending = ticket
             if pending is not None:
                 yield self.collect(pending, as_lists)
-            pending = ticket
-        if pending is not None:
-            yield self.collect(pending, as_lists)

@@ -288,18 +288,22 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
                     tot += len(r)
                 if cur:
                     yield cur
-        if isinstance(runner, EngineBatchRunner):
-            # arrays all the way (they pickle at memcpy speed through the gather); the per-read Python lists are built once, at
-            # the end, on rank 0.  Building them inside the pipeline loop measured SLOWER: 1.7 ms of list allocation per batch
-            # does not overlap with the GPU's 3.4 ms the way a 2 ms sleep or spin does (tools/prof_shard.py: 4.7 vs 3.4 ms
-            # per batch), so the loop stays allocation-free.
+        import torch.distributed as dist
+        n_ranks = world_size if world_size is not None else (
+            dist.get_world_size() if dist.is_available() and dist.is_initialized() else dist_env()[1])
+        if isinstance(runner, EngineBatchRunner) and n_ranks > 1:
+            # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
             return SpanTable.concat(list(runner.run(batches(), compact=True)))
+        # one rank: the per-read lists of batch k are built while the GPU runs batch k + 1 (0.3 ms per batch with the cyclic
+        # collector off, see batching.quiet_gc)
         out = []
         for res in runner.run(batches()):
             out.extend(res)
         return out
 
-    return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group)
+    from .batching import quiet_gc
+    with quiet_gc():
+        return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group)
 
 
 def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=None, rank=None, world_size=None,

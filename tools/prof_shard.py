@@ -14,7 +14,11 @@ junk = None
 def busy(ms):
     t = time.perf_counter()
     while (time.perf_counter() - t) * 1e3 < ms: pass
-for mode in ("arrays", "lists", "arrays+sleep2ms", "arrays+spin2ms", "arrays+tolist"):
+import gc
+for mode in ("arrays", "lists", "nogc:lists"):
+    gc.enable(); gc.unfreeze()
+    if mode.startswith("nogc"): gc.disable()
+    if mode.startswith("freeze"): gc.collect(); gc.freeze()
     for _ in pipe.run([base]*4, as_lists=False): pass
     torch.cuda.synchronize()
     ev = []
@@ -24,11 +28,19 @@ for mode in ("arrays", "lists", "arrays+sleep2ms", "arrays+spin2ms", "arrays+tol
         a = time.perf_counter(); tk = pipe.submit(base); b = time.perf_counter()
         if pending is not None:
             pending.done.synchronize(); c = time.perf_counter()
-            r = pipe.collect(pending, mode == "lists")
+            r = pipe.collect(pending, mode.endswith("lists"))
             if mode == "arrays+sleep2ms": time.sleep(0.002)
             if mode == "arrays+spin2ms": busy(2.0)
             if mode == "arrays+tolist":
                 junk = np.stack([r[1], r[2]], 1).tolist()
+            if mode == "arrays+stack":
+                for _ in range(20): junk = np.stack([r[1], r[2]], 1)
+            if mode == "arrays+tolist1d":
+                junk = (r[1].tolist(), r[2].tolist())
+            if mode == "arrays+bytearray":
+                for _ in range(50): junk = bytearray(1 << 20)
+            if mode.endswith("arrays+pylist"):
+                junk = [[i, i + 1] for i in range(10000)]
             d = time.perf_counter()
             ev.append((b - a, c - b, d - c))
         pending = tk
