@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _native as N
 from .batching import spans_from_runs
-from .infer import WINDOW_SIZE, padding_size_for
+from .infer import WINDOW_SIZE
 
 
 class _Ticket(object):
@@ -25,7 +25,7 @@ class _Ticket(object):
 
 
 class ReadPipeline(object):
-    def __init__(self, engine, max_samples_per_batch, threshold=0.5, min_run=15):
+    def __init__(self, engine, max_samples_per_batch, threshold=0.5, min_run=15, depth=2):
         import torch
         self.torch = torch
         self.eng = engine
@@ -35,13 +35,18 @@ class ReadPipeline(object):
         self.compute = torch.cuda.Stream(self.dev)
         self.copy = torch.cuda.Stream(self.dev)
         self.down = torch.cuda.Stream(self.dev)
-        self.out = [None, None]                                  # pinned (starts, ends, counts) per in-flight slot, grown on demand
-        self.inflight = [None, None]
+        # ``depth`` batches may be in flight (staged, launched, not yet collected).  Two is the measured optimum: with three the
+        # extra batch's side-stream kernels (normalisation, post-processing) crowd the forward pass of the batch in between
+        # (fp32 3.50 -> 3.68 ms per batch, bf16 1.00 -> 1.44 ms, tools/bench_e2e.py); short bf16 batches are better served
+        # by more reads per batch (1024 reads: 1.55 G samples/s host to host)
+        self.depth = max(2, int(depth))
+        self.out = [None] * self.depth                           # pinned (starts, ends, counts) per in-flight slot, grown on demand
+        self.inflight = [None] * self.depth
         self.cap = int(max_samples_per_batch)
         # two pinned staging buffers (double buffering)
-        self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(2)]
-        self.stage_free = [torch.cuda.Event() for _ in range(2)]
-        self.tab = [None, None]                                  # pinned offset / length tables per staging slot
+        self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(self.depth)]
+        self.stage_free = [torch.cuda.Event() for _ in range(self.depth)]
+        self.tab = [None] * self.depth                           # pinned offset / length tables per staging slot
         self.k = 0
 
     def submit(self, dac_reads):
@@ -56,20 +61,22 @@ class ReadPipeline(object):
             for ev in self.stage_free:
                 ev.synchronize()
             self.cap = total
-            self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(2)]
+            self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(self.depth)]
         dac_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
         np.cumsum(lengths, out=dac_off[1:])
-        n_win = np.array([(int(n) + padding_size_for(int(n))) // WINDOW_SIZE for n in lengths], dtype=np.int64)
+        n_win = lengths // WINDOW_SIZE + 1                      # infer.py:32-36: a multiple of 35 gets a full extra window
         win_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
         np.cumsum(n_win, out=win_off[1:])
-        slot = self.k & 1
+        slot = self.k % self.depth
         if self.inflight[slot] is not None:
-            raise RuntimeError("ReadPipeline: at most two batches in flight; collect() the oldest ticket first")
+            raise RuntimeError("ReadPipeline: at most %d batches in flight; collect() the oldest ticket first" % self.depth)
         self.k += 1
         self.stage_free[slot].synchronize()                     # previous H2D out of this staging buffer is done
         host = self.stage[slot].numpy()
-        for r, o in zip(dac_reads, dac_off[:-1]):
-            host[o:o + len(r)] = r
+        if len(dac_reads) == 1:
+            host[:total] = dac_reads[0]
+        elif total:
+            np.concatenate(dac_reads, out=host[:total], casting="unsafe")     # one C call instead of a Python loop over the reads
         # the four small tables go up from PINNED memory too, as one copy: a pageable source makes the runtime pin user
         # pages for the transfer, and host allocator activity (munmap) near such mappings stalls the GPU queues
         n_r = len(dac_reads)
@@ -150,14 +157,16 @@ class ReadPipeline(object):
         return [(spans[i], int(t.lengths[i])) for i in range(len(t.lengths))]
 
     def run(self, batches, as_lists=True):
-        """Iterate over batches (lists of int16 reads) with one batch in flight ahead; yields results."""
+        """Iterate over batches (lists of int16 reads) with up to ``depth - 1`` batches in flight ahead; yields results in order."""
+        from collections import deque
         from .batching import quiet_gc
-        pending = None
+        pending = deque()
         with quiet_gc():                      # list building must not trigger collections that walk the whole process
             for b in batches:
-                ticket = self.submit(b)
-                if pending is not None:
-                    yield self.collect(pending, as_lists)
-                pending = ticket
-            if pending is not None:
-                yield self.collect(pending, as_lists)
+                if len(pending) == self.depth:
+                    yield self.collect(pending.popleft(), as_lists)
+                pending.append(self.submit(b))
+                if len(pending) == self.depth:
+                    yield self.collect(pending.popleft(), as_lists)
+            while pending:
+                yield self.collect(pending.popleft(), as_lists)

@@ -220,7 +220,8 @@ class EngineBatchRunner(object):
         self.compact = bool(compact)
         from . import batching
         from .infer import is_dac, normalize_raw_signal
-        pending = None           # (ticket, host-path results or None)
+        from collections import deque
+        pending = deque()        # (ticket, host-path results or None), up to the pipeline's depth in flight
         for reads in batches:
             if all(is_dac(r) for r in reads):
                 item = (self.pipe.submit([np.ascontiguousarray(r, dtype=np.int16) for r in reads]), None)
@@ -229,11 +230,11 @@ class EngineBatchRunner(object):
                 max_windows = max(1, self.max_samples // WINDOW_SIZE)
                 item = (None, batching.infer_reads(self.engine, normed, max_windows=max_windows,
                                                    threshold=self.threshold, min_run=self.min_run))
-            if pending is not None:
-                yield self._finish(pending)
-            pending = item
-        if pending is not None:
-            yield self._finish(pending)
+            pending.append(item)
+            if len(pending) == self.pipe.depth:
+                yield self._finish(pending.popleft())
+        while pending:
+            yield self._finish(pending.popleft())
 
     def _finish(self, item):
         ticket, host_res = item
