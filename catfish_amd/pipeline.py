@@ -25,7 +25,7 @@ class _Ticket(object):
 
 
 class ReadPipeline(object):
-    def __init__(self, engine, max_samples_per_batch, threshold=0.5, min_run=15, depth=2):
+    def __init__(self, engine, max_samples_per_batch, threshold=0.5, min_run=15, depth=2, overlap_kernels=None):
         import torch
         self.torch = torch
         self.eng = engine
@@ -40,6 +40,13 @@ class ReadPipeline(object):
         # (fp32 3.50 -> 3.68 ms per batch, bf16 1.00 -> 1.44 ms, tools/bench_e2e.py); short bf16 batches are better served
         # by more reads per batch (1024 reads: 1.55 G samples/s host to host)
         self.depth = max(2, int(depth))
+        # where the small kernels run: True = normalisation on the copy stream and post-processing on the download stream, beside
+        # the neighbouring batches' forward passes; False = all kernels of a batch in order on the compute stream (only the
+        # H2D / D2H copies overlap).  CATFISH_PIPE_OVERLAP=0/1 overrides (A/B knob for tools/).
+        import os
+        if overlap_kernels is None and "CATFISH_PIPE_OVERLAP" in os.environ:
+            overlap_kernels = os.environ["CATFISH_PIPE_OVERLAP"] != "0"
+        self.overlap_kernels = True if overlap_kernels is None else bool(overlap_kernels)
         self.out = [None] * self.depth                           # pinned (starts, ends, counts) per in-flight slot, grown on demand
         self.inflight = [None] * self.depth
         self.cap = int(max_samples_per_batch)
@@ -94,36 +101,45 @@ class ReadPipeline(object):
             d_doff, d_woff = d_tab[0:n_r + 1], d_tab[n_r + 1:2 * n_r + 2]
             d_soff, d_len = d_tab[2 * n_r + 2:3 * n_r + 3], d_tab[3 * n_r + 3:4 * n_r + 3]
             self.stage_free[slot].record(self.copy)
-            # normalisation rides on the copy stream: it overlaps the previous batch's biGRU kernels (which leave
-            # wave slots and 15 KiB of LDS free on every CU) instead of delaying this batch's
             n_windows = int(win_off[-1])
+            h2d_done = torch.cuda.Event()
+            h2d_done.record(self.copy)
+        k_norm = self.copy if self.overlap_kernels else self.compute
+        k_post = self.down if self.overlap_kernels else self.compute
+        with torch.cuda.stream(k_norm):
+            # overlap mode: normalisation rides on the copy stream and overlaps the previous batch's biGRU kernels (which leave
+            # wave slots and 15 KiB of LDS free on every CU) instead of delaying this batch's
+            k_norm.wait_event(h2d_done)
             x = torch.empty(n_windows, WINDOW_SIZE, dtype=torch.float32, device=self.dev)
-            self.eng.normalize_device(d_dac, d_doff, d_woff, out=x, stream=self.copy)
+            self.eng.normalize_device(d_dac, d_doff, d_woff, out=x, stream=k_norm)
             copied = torch.cuda.Event()
-            copied.record(self.copy)
+            copied.record(k_norm)
         t = _Ticket()
-        with torch.cuda.stream(self.compute):                    # the compute stream only ever holds the forward pass
+        with torch.cuda.stream(self.compute):                    # overlap mode: the compute stream only ever holds the forward pass
             self.compute.wait_event(copied)
             probs = self.eng.infer_device(x, stream=self.compute)
             infer_done = torch.cuda.Event()
             infer_done.record(self.compute)
-        with torch.cuda.stream(self.down):                       # post-processing + D2H overlap the next batch's forward pass
-            self.down.wait_event(infer_done)
+        with torch.cuda.stream(k_post):                          # overlap mode: post-processing overlaps the next batch's forward pass
+            k_post.wait_event(infer_done)
             labels = self.eng.postprocess_device(probs, d_soff, d_len, threshold=self.threshold, min_run=self.min_run,
-                                                 stream=self.down)
+                                                 stream=k_post)
             max_runs = n_windows * WINDOW_SIZE // self.min_run + 16
             t.starts = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
             t.ends = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
             t.counts = torch.empty(2, dtype=torch.int64, device=self.dev)
             N.check(self.eng._lib.cf_spans(self.eng._handle, C.c_void_p(labels.data_ptr()), int(labels.numel()), max_runs,
                                            C.c_void_p(t.starts.data_ptr()), C.c_void_p(t.ends.data_ptr()),
-                                           C.c_void_p(t.counts.data_ptr()), C.c_void_p(self.down.cuda_stream)))
+                                           C.c_void_p(t.counts.data_ptr()), C.c_void_p(k_post.cuda_stream)))
+            spans_done = torch.cuda.Event()
+            spans_done.record(k_post)
         if self.out[slot] is None or self.out[slot][0].numel() < max_runs:
             self.out[slot] = (torch.empty(max_runs, dtype=torch.int64, pin_memory=True),
                               torch.empty(max_runs, dtype=torch.int64, pin_memory=True),
                               torch.empty(2, dtype=torch.int64, pin_memory=True))
         t.starts_h, t.ends_h, t.counts_h = self.out[slot]
         with torch.cuda.stream(self.down):                       # D2H of the (unsorted) run lists, whole capacity: ~1 MB
+            self.down.wait_event(spans_done)
             t.starts_h[:max_runs].copy_(t.starts, non_blocking=True)
             t.ends_h[:max_runs].copy_(t.ends, non_blocking=True)
             t.counts_h.copy_(t.counts, non_blocking=True)
