@@ -50,3 +50,18 @@ def f1(precision, recall):
     except ZeroDivisionError:
         print("Precision, recall or both are zero. Unable of calculating weighted F1.")
         return 0
+
+
+def weighted_f1(precision, recall, n, N):
+    """networks/trainingDB/metrics.py:95-113: F1 of one class weighted by its share n / N of the samples."""
+    try:
+        return 2 * n / N * (precision * recall) / (precision + recall)
+    except ZeroDivisionError:
+        print("Precision, recall or both are zero. Unable of calculating weighted F1.")
+        return 0
+
+
+def class_from_threshold(predicted_scores, threshold):
+    """networks/trainingDB/metrics.py:66-76 -> list of ints."""
+    import numpy as np
+    return (np.asarray(predicted_scores) >= threshold).astype(np.int64).tolist()

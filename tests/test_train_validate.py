@@ -89,6 +89,8 @@ def test_scores_from_confusion_counts():
     assert metrics.precision_recall(0, 0, 0) == (0, 0)
     assert metrics.calculate_accuracy(1, 1, 1, 1) == 0.5 and metrics.calculate_accuracy(0, 0, 0, 0) == 0
     assert metrics.f1(0.5, 0.5) == 0.5 and metrics.f1(0, 0) == 0
+    assert metrics.weighted_f1(0.5, 0.5, 10, 40) == 0.125 and metrics.weighted_f1(0, 0, 1, 2) == 0
+    assert metrics.class_from_threshold([0.1, 0.5, 0.9], 0.5) == [0, 1, 1]
 
 
 def test_loss_from_logits_survives_saturation():
