@@ -1944,7 +1944,8 @@ extern "C" int64_t cf_res_train_param_floats(int32_t n_blocks) {
 
 extern "C" int64_t cf_res_train_workspace_floats(int32_t n_blocks, int64_t n_windows) {
     if (n_blocks < 1 || 4 * n_blocks > RT_MAX_UNITS || n_windows <= 0) return 0;
-    return ((n_windows + RT_WIN - 1) / RT_WIN) * (int64_t)rt_make_layout(n_blocks).off[4 * n_blocks];
+    const int win = rt_win_for(n_windows);
+    return ((n_windows + win - 1) / win) * (int64_t)rt_make_layout(n_blocks).off[4 * n_blocks];
 }
 
 extern "C" int cf_res_train_forward(cf_model* m, int32_t n_blocks, const float* params, const float* x, float* z_stash, float* out,
@@ -1954,9 +1955,10 @@ extern "C" int cf_res_train_forward(cf_model* m, int32_t n_blocks, const float* 
     int rc = res_train_ok(m, n_blocks);
     if (rc != CF_OK) return rc;
     HIP_TRY(hipSetDevice(m->device));
-    const int n_wg = (int)((n_windows + RT_WIN - 1) / RT_WIN);
+    const int win = rt_win_for(n_windows);
+    const int n_wg = (int)((n_windows + win - 1) / win);
     hipLaunchKernelGGL(res_train_fwd_kernel, dim3(n_wg), dim3(RT_THREADS), RT_FWD_LDS_BYTES, reinterpret_cast<hipStream_t>(stream), x, params,
-                       z_stash, out, rt_make_layout(n_blocks), (int)n_windows, n_blocks, m->hp.bn_epsilon);
+                       z_stash, out, rt_make_layout(n_blocks), (int)n_windows, n_blocks, m->hp.bn_epsilon, win);
     HIP_TRY(hipGetLastError());
     return CF_OK;
 }
@@ -1974,9 +1976,10 @@ extern "C" int cf_res_train_backward(cf_model* m, int32_t n_blocks, const float*
     const int lds_bytes = RT_BWD_LDS_BYTES;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const rt_layout L = rt_make_layout(n_blocks);
-    const int n_wg = (int)((n_windows + RT_WIN - 1) / RT_WIN);
+    const int win = rt_win_for(n_windows);
+    const int n_wg = (int)((n_windows + win - 1) / win);
     hipLaunchKernelGGL(res_train_bwd_kernel, dim3(n_wg), dim3(RT_THREADS), lds_bytes, s, x, params, z_stash, d_out, workspace, L,
-                       (int)n_windows, n_blocks, m->hp.bn_epsilon);
+                       (int)n_windows, n_blocks, m->hp.bn_epsilon, win);
     HIP_TRY(hipGetLastError());
     const int nf = L.off[4 * n_blocks];
     hipLaunchKernelGGL(res_train_reduce_kernel, dim3((nf + 63) / 64), dim3(256), 0, s, workspace, grads, nf, n_wg);

@@ -15,8 +15,10 @@
 // moving_mean[32] | moving_variance[32]  (TensorFlow layouts), units back to back; cin = 1 for units 0 and 1.
 #pragma once
 
-#define RT_WIN 2
+#define RT_WIN 2                          // windows per workgroup (LDS is sized for it); small batches run 1 per workgroup
 #define RT_POS (RT_WIN * CF_T)
+#define RT_SMALL_BATCH 1024               // up to this many windows: one window per workgroup (twice the workgroups, half the chain)
+static inline int rt_win_for(int64_t n_windows) { return n_windows <= RT_SMALL_BATCH ? 1 : RT_WIN; }
 #define RT_THREADS 256
 #define RT_PG (RT_THREADS / 32)
 #define RT_MAX_UNITS 16
@@ -98,15 +100,15 @@ __global__ __launch_bounds__(RT_THREADS) void res_train_fwd_kernel(const float* 
                                                                    const float* __restrict__ prm,    // parameter buffer
                                                                    float* __restrict__ Z,            // [units][N*35][32]
                                                                    float* __restrict__ out,          // [N*35][32]
-                                                                   rt_layout L, int n_windows, int n_blocks, float eps) {
+                                                                   rt_layout L, int n_windows, int n_blocks, float eps, int win) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* BA = lds;
     float* B1 = BA + RT_POS * 32;
     float* B2 = B1 + RT_POS * 32;
     float* BS = B2 + RT_POS * 32;
     const int co = threadIdx.x & 31, pg = threadIdx.x >> 5;
-    const int w0 = blockIdx.x * RT_WIN;
-    const int npos = min(RT_WIN, n_windows - w0) * CF_T;
+    const int w0 = blockIdx.x * win;
+    const int npos = min(win, n_windows - w0) * CF_T;
     const int64_t g0 = (int64_t)w0 * CF_T;
     const int64_t NP = (int64_t)n_windows * CF_T;
     for (int p = threadIdx.x; p < npos; p += RT_THREADS) BA[p * 32] = x[g0 + p];
@@ -221,7 +223,7 @@ __device__ __forceinline__ void rt_load_wrow(const float* W, int ci, float (&wro
 __global__ __launch_bounds__(RT_THREADS) void res_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
                                                                    const float* __restrict__ Z, const float* __restrict__ dout,
                                                                    float* __restrict__ P,      // [workgroup][grad floats]
-                                                                   rt_layout L, int n_windows, int n_blocks, float eps) {
+                                                                   rt_layout L, int n_windows, int n_blocks, float eps, int win) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* BA = lds;                       // block input
     float* O1 = BA + RT_POS * 32;          // relu(BN(conv1(a)))      -> later d/d(its BN output)
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(RT_THREADS) void res_train_bwd_kernel(const float* 
     float* DZ = GB + RT_POS * 32;
     float* D = DZ + RT_POS * 32;           // 3 * 32 * 32 + 96 reduction scratch
     const int ch = threadIdx.x & 31, pg = threadIdx.x >> 5;
-    const int w0 = blockIdx.x * RT_WIN;
-    const int npos = min(RT_WIN, n_windows - w0) * CF_T;
+    const int w0 = blockIdx.x * win;
+    const int npos = min(win, n_windows - w0) * CF_T;
     const int64_t g0 = (int64_t)w0 * CF_T;
     const int64_t NP = (int64_t)n_windows * CF_T;
     float* Pwg = P + (size_t)blockIdx.x * L.off[4 * n_blocks];
