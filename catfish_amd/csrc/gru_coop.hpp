@@ -16,6 +16,11 @@ static inline int cf_xproj_chunks(int n_tiles) { return n_tiles <= 8 ? CF_T : 7;
 #ifndef CF_COOP_PF
 #define CF_COOP_PF 4        // A-fragment prefetch depth (k-steps) of the cooperative forward kernel
 #endif
+// Diagnostic build: s_memtime cycles of the four segments of a step (h read + r/u MFMAs | r, r*h, barrier | c MFMAs | u, c, h', barrier),
+// summed over the 35 steps by wave 0 and written as int64 [dir][tile][8] to the dense-partial buffer of the non-LAST kernels
+#ifndef CF_COOP_STAMP
+#define CF_COOP_STAMP 0
+#endif
 
 // HOIST: the x projection (bias + Wx^T x_t, all 35 steps) was computed by gru_xproj_kernel into XP; the step then
 // starts from those accumulators -- the same fp32 values the in-kernel x part produces, so results are unchanged.
@@ -75,8 +80,12 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) fetch(p, ring[p]);
+    long long st_[4] = {0, 0, 0, 0};
+    const long long st_begin = CF_COOP_STAMP ? (long long)__builtin_amdgcn_s_memtime() : 0;
     for (int s = 0; s < CF_T; ++s) {
         const int t = dir ? (CF_T - 1 - s) : s;
+        long long ta_ = CF_COOP_STAMP ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define CF_CSTAMP(idx) if (CF_COOP_STAMP) { const long long tb_ = (long long)__builtin_amdgcn_s_memtime(); st_[idx] += tb_ - ta_; ta_ = tb_; }
         f32x4 hf[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) hf[m] = hx[m * 64];
@@ -114,11 +123,13 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
             au = MFMA16(a1, b, au);
             __builtin_amdgcn_sched_barrier(0);
         }
+        CF_CSTAMP(0);
         f32x4 rh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ar[r] = cf_sigmoid_pre(ar[r]); rh[r] = ar[r] * hown[r]; }
         rx[W * 64] = rh;
         __syncthreads();
+        CF_CSTAMP(1);
         f32x4 rf[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) rf[m] = rx[m * 64];
@@ -131,6 +142,7 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
             acnd = MFMA16(a0, b, acnd);
             __builtin_amdgcn_sched_barrier(0);
         }
+        CF_CSTAMP(2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float u = cf_sigmoid_pre(au[r]);
@@ -158,9 +170,16 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
             const f32x4 wd = *(reinterpret_cast<const f32x4*>(lds + DENSE) + q + W * 4);
             float p = wd.x * hown.x;
             p = fmaf(wd.y, hown.y, p); p = fmaf(wd.z, hown.z, p); p = fmaf(wd.w, hown.w, p);
-            P[((((int64_t)dir * n_tiles + tile) * CF_T + t) * 4 + W) * 64 + lane] = p;
+            if (!CF_COOP_STAMP) P[((((int64_t)dir * n_tiles + tile) * CF_T + t) * 4 + W) * 64 + lane] = p;
         }
         __syncthreads();
+        CF_CSTAMP(3);
+#undef CF_CSTAMP
+    }
+    if (CF_COOP_STAMP && !LAST && W == 0 && lane == 0 && P) {
+        long long* o = reinterpret_cast<long long*>(P) + ((int64_t)dir * n_tiles + tile) * 8;
+        o[0] = st_[0]; o[1] = st_[1]; o[2] = st_[2]; o[3] = st_[3];
+        o[4] = (long long)__builtin_amdgcn_s_memtime() - st_begin;
     }
 }
 
