@@ -107,8 +107,8 @@ def mid_roofline(kern, precision, samples_per_launch, traffic=None, traffic_sour
     ms, n = kern["gru_layer_mid"]
     achieved = FLOP_PER_SAMPLE_GRU128 * samples_per_launch / (ms / n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    kname = "gru_layer_kernel<128,false>" if precision == "fp32" else \
-        "gru_layer_bf16_kernel<128,false,%d>" % (2 if precision == "bf16x3" else 1)
+    kname = {"fp32": "gru_layer_kernel<128,false>", "bf16x3": "gru_layer_bf16_kernel<128,false,2>",
+             "bf16": "gru_bf16_pipe_kernel<128,false>"}[precision]
     return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": ms / n,
             "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_launch}
@@ -195,7 +195,7 @@ def leg_config4(weights, local_rank, torch):
         mid_s = ms / rep * 1e-3
         ach = FLOP_PER_SAMPLE_GRU128 * total / mid_s / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                "traffic": None, "kernel": "gru_layer_bf16_kernel<128,false,1>", "launches_per_repetition": n // rep,
+                "traffic": None, "kernel": "gru_bf16_pipe_kernel<128,false>", "launches_per_repetition": n // rep,
                 "ms_per_repetition": ms / rep}
     return {"workload": "configs[3]: %d reads, lengths LogUniform[512,16384] (seed 2), DAC squiggles, length-bucketed packed "
                         "launches of <= %d windows, bf16 biGRU arithmetic, device-resident" % (CONFIG4_READS, max_windows),
