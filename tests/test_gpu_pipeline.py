@@ -168,6 +168,55 @@ def test_full_size_properties(model):
     assert np.abs(got - want).max() < 1e-4
 
 
+def test_bf16_full_size_properties(ckpt_weights):
+    """BASELINE configs[3]'s dtype at the benchmark's launch size (30 208 windows, the software-pipelined bf16 kernel):
+    run-to-run determinism, window-permutation equivariance and batch-split invariance, bit-exact (a window's arithmetic
+    does not depend on its tile-mates), plus a sample against the fp64 oracle at the bf16 tolerance."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.engine import HipEngine
+    n = 256 * 118
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=n, precision="bf16")
+    try:
+        g = torch.Generator(device="cpu").manual_seed(1)
+        x = torch.randn(n, 35, generator=g).mul_(1.5).cuda()
+        a = eng.infer_device(x).clone()
+        assert torch.equal(a, eng.infer_device(x))
+        perm = torch.randperm(n, generator=g).cuda()
+        c = eng.infer_device(x[perm].contiguous()).view(n, 35)
+        assert torch.equal(c, a.view(n, 35)[perm])
+        part = eng.infer_device(x[: n // 2 + 13].contiguous())
+        assert torch.equal(part, a[: (n // 2 + 13) * 35])
+        assert torch.isfinite(a).all() and (a >= 0).all() and (a <= 1).all()
+        idx = torch.randint(0, n, (48,), generator=g)
+        want = oracle.forward(x[idx.cuda()].cpu().numpy(), ckpt_weights, np.float64).reshape(48, 35)
+        got = a.view(n, 35)[idx.cuda()].cpu().numpy()
+        assert np.abs(got - want).max() < 3e-2 and np.mean((got >= 0.5) == (want >= 0.5)) > 0.99
+        eng.check_error()
+    finally:
+        eng.close()
+
+
+def test_logits_output_and_pipeline_options(model, ckpt_weights):
+    """cf_infer_logits on device buffers: sigmoid(logits) == probs; the streaming pipeline gives the same spans with three
+    batches in flight and with every kernel of a batch on the compute stream (the two knobs of ReadPipeline)."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.pipeline import ReadPipeline
+    x = torch.randn(300, 35, device="cuda")
+    logits = torch.empty(300 * 35, device="cuda")
+    probs = model.engine.infer_device(x, logits=logits)
+    assert torch.allclose(torch.sigmoid(logits), probs, atol=1e-6)
+    assert torch.equal(probs, model.engine.infer_device(x))
+    lens = [4096, 700, 35, 5000, 36, 2048, 999, 1234, 4096, 512]
+    dacs = [oracle.synthetic_dac(1, n, seed=800 + i)[0] for i, n in enumerate(lens)]
+    batches = [dacs[0:3], dacs[3:5], dacs[5:8], dacs[8:10], dacs[2:6]]
+    ref = [r for res in ReadPipeline(model.engine, 12000).run(batches) for r in res]
+    for kw in (dict(depth=3), dict(overlap_kernels=False), dict(depth=4, overlap_kernels=False)):
+        got = [r for res in ReadPipeline(model.engine, 12000, **kw).run(batches) for r in res]
+        assert got == ref, kw
+    w_spans, w_len, _ = oracle.infer_read(oracle.normalize_raw_signal(dacs[0]), ckpt_weights, np.float32)
+    assert ref[0] == (w_spans, w_len)
+
+
 def test_extreme_inputs_saturate_cleanly(model):
     x = np.zeros((32, 35), np.float32)
     x[0] = 1e4; x[1] = -1e4; x[2, ::2] = 300; x[3] = np.linspace(-50, 50, 35)

@@ -208,3 +208,25 @@ def test_product_never_imports_oracle():
         if name.endswith(".py"):
             src = open(os.path.join(pkg, name)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), name
+
+
+def test_quiet_gc_restores_the_collector():
+    """batching.quiet_gc: the cyclic collector is off inside (list building stays cheap next to torch's object graph) and
+    back to its previous state afterwards, also when it was off before and when the body raises."""
+    import gc
+    was = gc.isenabled()
+    try:
+        gc.enable()
+        with batching.quiet_gc():
+            assert not gc.isenabled()
+        assert gc.isenabled()
+        with pytest.raises(RuntimeError):
+            with batching.quiet_gc():
+                raise RuntimeError("boom")
+        assert gc.isenabled()
+        gc.disable()
+        with batching.quiet_gc():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable() if was else gc.disable()
