@@ -37,6 +37,7 @@ FLOP_PER_SAMPLE = 389504            # SURVEY.md 8d / BASELINE.md 2 (2 x 194 752 
 FLOP_PER_SAMPLE_GRU128 = 2 * 2 * (128 + 64) * 192   # one CIN=128 biGRU layer: 2 dirs x 2 FLOP x 192x192 MAC
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md, HBM3E peak (about 6.3 TB/s is achievable on a copy)
 SHARDED_READS_PER_RANK = 12500      # BASELINE configs[2]: 100 000 reads over 8 GPUs
 CONFIG4_READS = 2048                # BASELINE configs[3] names 10 000 reads; the informational leg times a 2048-read sample
 
@@ -87,16 +88,17 @@ def cpu_baseline():
     return res
 
 
-def traffic_record():
-    """HBM bytes per launch of the dominant kernel from the last FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json,
-    written by tools/collect_traffic.sh): a STORED measurement -- PMC counters cannot be read from inside this
-    process -- so the line says which commit and command it came from."""
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(tpath):
+def traffic_record(precision="fp32"):
+    """HBM bytes per launch of the dominant kernel from the last FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json for
+    fp32, profiles/traffic_bf16.json for bf16, written by tools/collect_traffic.sh): a STORED measurement -- PMC counters
+    cannot be read from inside this process -- so the line says which commit and command it came from."""
+    name = {"fp32": "traffic.json", "bf16": "traffic_bf16.json"}.get(precision)
+    tpath = os.path.join(ROOT, "profiles", name) if name else None
+    if tpath is None or not os.path.exists(tpath):
         return None, None
     with open(tpath) as fh:
         t = json.load(fh)
-    src = {"file": "profiles/traffic.json", "kind": "stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run",
+    src = {"file": "profiles/" + name, "kind": "stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run",
            "commit": t.get("commit"), "collected": t.get("collected"), "kernel_avg_ms_at_collection": t.get("kernel_avg_ms")}
     return t, src
 
@@ -105,13 +107,22 @@ def mid_roofline(kern, precision, samples_per_launch, traffic=None, traffic_sour
     if "gru_layer_mid" not in kern:
         return None
     ms, n = kern["gru_layer_mid"]
+    if traffic is None and traffic_source is None:
+        t, traffic_source = traffic_record(precision)
+        traffic = t.get("gru_layer_mid_bytes_per_launch") if t else None
     achieved = FLOP_PER_SAMPLE_GRU128 * samples_per_launch / (ms / n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     kname = {"fp32": "gru_layer_kernel<128,false>", "bf16x3": "gru_layer_bf16_kernel<128,false,2>",
              "bf16": "gru_bf16_pipe_kernel<128,false>"}[precision]
-    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": ms / n,
             "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_launch}
+    if traffic:
+        # the other roof, for the reader: measured fabric bytes of this kernel over its live launch time against 8 TB/s
+        # (the bf16 mid layer moves 768 B per sample and sits nearer this roof than the matrix one)
+        roof["hbm_view"] = {"achieved": traffic / (ms / n * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": traffic / (ms / n * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    return roof
 
 
 def timed_steps(eng, batches, outs, n, torch):
@@ -360,11 +371,7 @@ def main():
         min_match = 1.0 if args.precision != "bf16" else 0.998
         parity_ok = bool(np.isfinite(got).all() and max_dp < gate and match >= min_match)
 
-        traffic, traffic_src = (None, None)
-        if args.precision == "fp32":
-            t, traffic_src = traffic_record()
-            traffic = t.get("gru_layer_mid_bytes_per_launch") if t else None
-        roof = mid_roofline(kern, args.precision, samples_per_step, traffic, traffic_src)
+        roof = mid_roofline(kern, args.precision, samples_per_step)
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         result = {
             "metric": "signal samples/s classified",
