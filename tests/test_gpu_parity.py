@@ -206,6 +206,42 @@ def test_fused_single_launch_matches_per_layer_launches(ckpt_weights, n_windows)
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_million_window_launch_index_arithmetic(ckpt_weights, precision):
+    """One launch of 1 920 021 windows (67 M samples, 86 GB of workspace out of the card's 288 GB): the activation buffers
+    cross 2^31 bytes (tile 7 490), 2^31 floats (tile 29 960) and 2^31 16-byte fragments (tile 119 837).  Windows either
+    side of each boundary, the ragged last tile and a random sample must equal the same windows run as a small launch,
+    bit for bit (a window's arithmetic does not depend on where it sits), and a few are checked against the fp64 oracle."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.engine import HipEngine
+    n = 119837 * 16 + 2629                                     # 1 920 021
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of free device memory")
+    big = HipEngine(ckpt_weights, device=0, max_windows_per_pass=n, precision=precision)
+    small = HipEngine(ckpt_weights, device=0, max_windows_per_pass=4096, precision=precision)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(9)
+        x = torch.randn(n, 35, device="cuda", generator=g).mul_(1.5)
+        got = big.infer_device(x).view(n, 35)
+        big.check_error()
+        assert torch.isfinite(got).all()
+        cuts = [0, 7490 * 16, 29960 * 16, 119837 * 16, n // 2 + 5]
+        for c in cuts:
+            lo, hi = max(0, c - 77), min(n, c + 83)
+            assert torch.equal(small.infer_device(x[lo:hi].contiguous()).view(hi - lo, 35), got[lo:hi]), (precision, c)
+        assert torch.equal(small.infer_device(x[n - 300:].contiguous()).view(300, 35), got[n - 300:])
+        idx = torch.randint(0, n, (2048,), device="cuda", generator=g)
+        assert torch.equal(small.infer_device(x[idx].contiguous()).view(2048, 35), got[idx])
+        small.check_error()
+        pick = torch.tensor([0, 7490 * 16 + 1, 29960 * 16 - 1, 119837 * 16, 119837 * 16 + 17, n - 1], device="cuda")
+        want = oracle.forward(x[pick].cpu().numpy(), ckpt_weights, np.float64).reshape(len(pick), 35)
+        assert np.abs(got[pick].cpu().numpy() - want).max() < (TOL if precision == "fp32" else 3e-2)
+    finally:
+        big.close(); small.close()
+
+
+@pytest.mark.timeout(900)
 def test_fused_auto_regime_is_bit_identical_and_error_free(ckpt_weights):
     """The regime the CLI ships for big jobs (cli.py: 131 072-window launches, fuse_layers = auto): 768+ eight-tile
     groups per layer on 256 CUs, i.e. three layer pools of workgroups that cannot all be resident, layer l+1 waiting
