@@ -382,6 +382,28 @@ def test_streaming_pipeline_matches_oracle(model, ckpt_weights):
     assert (spans, n) == (w_spans, w_len)
 
 
+def test_ultra_long_read_through_the_pipeline(model, tmp_path):
+    """One 3 000 017-sample read (ultra-long nanopore reads are millions of samples): 85 715 windows, more than the
+    engine's launch capacity, so cf_infer runs it in several passes; the staging buffers grow; one workgroup finds the
+    exact medians of 3 M samples.  The device route (int16 -> cf_normalize -> cf_infer -> cf_postprocess -> cf_spans)
+    must give the same spans as the host route of infer_class_from_signal (numpy normalisation in float64, cf_infer_host,
+    host post-processing) on the same read."""
+    from catfish_amd import infer as cinfer
+    from catfish_amd.pipeline import ReadPipeline
+    n = 3000017
+    rng = np.random.default_rng(5)
+    level = np.repeat(rng.normal(500, 60, size=n // 9 + 1), 9)[:n]
+    dac = np.clip(level + rng.normal(0, 8, size=n), 0, 2047).astype(np.int16)
+    path = tmp_path / "long.npy"
+    np.save(path, dac)
+    want_spans, want_len = cinfer.infer_class_from_signal(str(path), model)
+    assert want_len == n
+    pipe = ReadPipeline(model.engine, max_samples_per_batch=100000)
+    (spans, length), = pipe.collect(pipe.submit([dac]))
+    assert length == n and spans == want_spans and len(spans) > 100
+    model.engine.check_error()
+
+
 @pytest.mark.parametrize("n", [40, 2100])
 def test_native_gru_training_kernels_match_torch_autograd(n):
     """cf_gru_train_forward/backward (+ library GEMMs for dW) against torch autograd of the restated graph:
