@@ -921,6 +921,8 @@ __global__ __launch_bounds__(256) void normalize_kernel(const int16_t* __restric
 // ==========================================================================================
 // Host side
 // ==========================================================================================
+#include "generic.hpp"
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string& msg) {
@@ -967,6 +969,7 @@ struct cf_model {
         bool last_res_fused = false;          // the last pass ran blocks 0 and 1 as one launch: block 0's output was never stored
     };
     std::vector<Slot> slots;
+    cf_generic* gen = nullptr;                // any-size path (generic.hpp): set when the geometry is not the shipped 64 / 32
     int fuse = 0;                             // all GRU layers in one launch (fp32 path, n_layers <= 3): 0 never, 1 always,
                                               // 2 auto = only for passes of >= 6 rounds, where the dynamic queues pay
     float* d_xp = nullptr;                    // hoisted x projection of small calls: [xp_tiles][35][2][12][64] f32x4
@@ -1118,6 +1121,10 @@ static int upload(const std::vector<float>& host, float** dev) {
     return CF_OK;
 }
 
+static bool gen_wanted(const cf_hparams* hp);
+static int gen_build(cf_model* m, const cf_weights* w);
+static void gen_destroy(cf_generic* g);
+
 extern "C" void cf_model_destroy(cf_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
@@ -1132,6 +1139,7 @@ extern "C" void cf_model_destroy(cf_model* m) {
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    gen_destroy(m->gen);
     if (m->d_xp) (void)hipFree(m->d_xp);
     if (m->d_host_x) (void)hipFree(m->d_host_x);
     if (m->h_err) (void)hipHostFree(m->h_err);
@@ -1145,11 +1153,10 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
     if (!w || !hp || !out) return fail(CF_ERR_INVALID, "cf_model_create: null argument");
     *out = nullptr;
     if (hp->window != CF_T) return fail(CF_ERR_INVALID, "window must be 35 (rnn_class.py:27)");
-    if (hp->layer_size != CF_H || hp->n_layers < 1)
-        return fail(CF_ERR_INVALID, "kernels are specialised for layer_size = 64, n_layers >= 1");
-    if (hp->n_layers_res < 0 || (hp->n_layers_res > 0 && hp->layer_size_res != CF_C))
-        return fail(CF_ERR_INVALID, "kernels are specialised for layer_size_res = 32 (ResNetRNN) or n_layers_res = 0 (RNN)");
-    if (hp->n_layers_res == 0 && hp->precision != CF_PREC_FP32)
+    if (hp->n_layers < 1 || hp->n_layers_res < 0) return fail(CF_ERR_INVALID, "n_layers must be >= 1 and n_layers_res >= 0");
+    // the shipped geometry (64 GRU units, 32 conv channels) runs on the tuned kernels, every other one on generic.hpp
+    const bool generic = gen_wanted(hp);
+    if (!generic && hp->n_layers_res == 0 && hp->precision != CF_PREC_FP32)
         return fail(CF_ERR_INVALID, "the plain RNN type (n_layers_res = 0) is only built for CF_PREC_FP32");
     if ((hp->n_layers_res > 0 && !w->conv) || !w->gru || !w->dense_kernel || !w->dense_bias)
         return fail(CF_ERR_INVALID, "cf_weights has null members");
@@ -1166,6 +1173,13 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
     m->np = hp->precision == CF_PREC_FP32 ? 0 : (hp->precision == CF_PREC_BF16X3 ? 2 : 1);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
+    if (generic) {
+        m->dense_bias = w->dense_bias[0];
+        const int grc = gen_build(m, w);
+        if (grc != CF_OK) { cf_model_destroy(m); return grc; }
+        *out = m;
+        return CF_OK;
+    }
     int rc = CF_OK;
     // residual blocks
     for (int b = 0; b < hp->n_layers_res && rc == CF_OK; ++b) {
@@ -1321,6 +1335,8 @@ static int prof_end(cf_model* m, hipStream_t s, size_t idx) {
 // Waves per workgroup: 8 (two per SIMD) when the pass fills the chip; fewer for small calls (a single read is
 // 8 tiles x 2 directions) so that the tiles spread over more CUs instead of sharing SIMDs -- the 35-step
 // chain is latency-bound there.
+#include "generic_host.hpp"
+
 static int pick_waves(int n_tile_tasks, int n_cu) {
     int w = (n_tile_tasks + n_cu - 1) / n_cu;
     return w <= 1 ? 1 : (w <= 2 ? 2 : (w <= 4 ? 4 : 8));
@@ -1560,6 +1576,7 @@ extern "C" int cf_check_error(cf_model* m) {
 extern "C" int cf_launch_regimes(const cf_model* m, int64_t out[4]) {
     if (!m || !out) return fail(CF_ERR_INVALID, "cf_launch_regimes: null argument");
     out[0] = m->n_cu;
+    if (m->gen) { out[1] = out[2] = out[3] = 0; return CF_OK; }       // one launch shape at every size
     out[1] = (int64_t)m->xp_tiles * CF_TILE;
     out[2] = m->np == 0 ? (int64_t)m->n_cu * CF_TILE : 0;
     out[3] = m->fuse == 1 ? 1 : (m->fuse == 2 ? ((int64_t)8 * cf_fuse_min_groups(m->n_cu) - 8) * CF_TILE + 1 : 0);
@@ -1575,6 +1592,14 @@ extern "C" int cf_infer_logits(cf_model* m, const float* x, int64_t n_windows, f
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     m->prof = m->prof_every > 0 && (m->prof_calls++ % m->prof_every) == 0;
+    if (m->gen) {
+        for (int64_t off = 0; off < n_windows; off += m->cap_windows) {
+            const int64_t n = std::min(m->cap_windows, n_windows - off);
+            const int rc = gen_run_pass(m, x + off * CF_T, n, probs ? probs + off * CF_T : nullptr, logits ? logits + off * CF_T : nullptr, s);
+            if (rc != CF_OK) return rc;
+        }
+        return CF_OK;
+    }
     const int n_slots = (int)m->slots.size();
     // sub-batch size: split the call evenly over the slots, in whole 8-tile groups (128 windows)
     int64_t chunk = m->cap_windows;
@@ -1744,6 +1769,7 @@ extern "C" int cf_gru_pack_map(int32_t cin, int32_t backward, int32_t* idx, floa
 
 static int train_cin_ok(const cf_model* m, int cin) {
     if (m->np != 0) return fail(CF_ERR_INVALID, "training kernels need a CF_PREC_FP32 model");
+    if (m->hp.layer_size != CF_H) return fail(CF_ERR_INVALID, "training kernels: layer_size 64 only (other sizes train on the torch-autograd path)");
     if (cin != CF_C && cin != 2 * CF_H) return fail(CF_ERR_INVALID, "training kernels: cin must be 32 or 128");
     return CF_OK;
 }
@@ -2006,6 +2032,7 @@ extern "C" int cf_train_head(cf_model* m, const float* y_frag, const float* dens
     if (!m || !y_frag || !dense_kernel || !dense_bias || !labels || !dy_frag || !workspace || !grads || !loss)
         return fail(CF_ERR_INVALID, "cf_train_head: null argument");
     if (n_windows <= 0) return fail(CF_ERR_INVALID, "cf_train_head: n_windows must be positive");
+    if (m->hp.layer_size != CF_H) return fail(CF_ERR_INVALID, "cf_train_head: layer_size 64 only");
     if (workspace_floats < cf_train_head_workspace_floats(m, n_windows))
         return fail(CF_ERR_INVALID, "cf_train_head: workspace too small (see cf_train_head_workspace_floats)");
     HIP_TRY(hipSetDevice(m->device));
@@ -2085,6 +2112,7 @@ extern "C" const char* cf_profile_slot_name(int slot) {
 // ---- debug hook --------------------------------------------------------------------------
 extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host) {
     if (!m || !out_host) return fail(CF_ERR_INVALID, "cf_debug_stage: null argument");
+    if (m->gen) return fail(CF_ERR_INVALID, "cf_debug_stage: not available on the any-size path");
     if (m->np > 0 && stage != 100) return fail(CF_ERR_INVALID, "cf_debug_stage: only available with CF_PREC_FP32");
     const cf_model::Slot& sl = m->slots[0];
     if (n_windows <= 0 || (stage != 100 && n_windows > sl.last_windows)) return fail(CF_ERR_INVALID, "cf_debug_stage: n_windows exceeds slot 0's last pass");

@@ -1,0 +1,236 @@
+// Any-size inference path: the model classes take layer_size / layer_size_res from {16, 32, 64, 128, 256} and any depth
+// (networks/train_validate.py:70-78, catfish/models/rnn_class.py:13-18, resnet_class.py:9-14); the tuned kernels of
+// catfish_hip.hip are specialised for the shipped checkpoint (64 GRU units, 32 conv channels).  Every other geometry runs
+// here: the same fragment layout [tile][t][feature tile][lane][4] and the same fp32 MFMA (v_mfma_f32_16x16x4_f32, the
+// previous layer's D tile fed back as the B operand), but with run-time sizes -- weights stream from global memory (L2 /
+// Infinity Cache resident: at most 2.4 MB per direction and layer) as pre-tiled A fragments instead of living in LDS, the
+// biGRU state of a tile (h, r.h, h') lives in LDS, and one launch computes one conv or one biGRU layer.
+// Included by catfish_hip.hip (needs f32x4, MFMA16, CF_T, CF_TILE, CF_GATE_SCALE, CF_CAND_SCALE).
+#pragma once
+
+// A pack of a matrix with K inputs (K16 blocks of 16) and M outputs (M16 tiles): f32x4 P[(mo * K16 + kb) * 64 + lane] =
+// W[in = 16 kb + 4 (lane >> 4) + i][out = 16 mo + (lane & 15)], i = 0..3: component i is the A operand of the MFMA whose B
+// operand is register i of input tile kb (lane quarter q of that register carries feature 16 kb + 4 q + i).
+
+// ---- block 0's two k = 1 convs on the raw sample (Cin = 1): shortcut and first conv, resnet_class.py:60-66 ---------------
+__global__ __launch_bounds__(256) void gen_first_kernel(const float* __restrict__ x_nat, const f32x4* __restrict__ wb /*[4][Co16][64]: w_sc, b_sc, w_1, b_1*/,
+                                                        f32x4* __restrict__ SC, f32x4* __restrict__ O1, int64_t n_windows, int n_tiles, int Co16) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;            // (tile, t, mo, lane)
+    const int64_t total = (int64_t)n_tiles * CF_T * Co16 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t r = idx >> 6;
+    const int mo = (int)(r % Co16);
+    const int64_t tt = r / Co16;
+    const int t = (int)(tt % CF_T);
+    const int64_t w = (tt / CF_T) * CF_TILE + (lane & 15);
+    const float xv = w < n_windows ? x_nat[w * CF_T + t] : 0.f;
+    const f32x4 ws = wb[(0 * Co16 + mo) * 64 + lane], bs = wb[(1 * Co16 + mo) * 64 + lane];
+    const f32x4 w1 = wb[(2 * Co16 + mo) * 64 + lane], b1 = wb[(3 * Co16 + mo) * 64 + lane];
+    f32x4 sc, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = fmaf(ws[j], xv, bs[j]);
+        o1[j] = fmaxf(fmaf(w1[j], xv, b1[j]), 0.f);
+    }
+    SC[idx] = sc;
+    O1[idx] = o1;
+}
+
+// ---- one conv1d (k = 1 or 3, padding SAME inside the 35-sample window) with folded batch norm ---------------------------------
+// One wave per (tile, position); output tiles two at a time (two independent MFMA chains sharing the B operand).
+__global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__ W /*[taps][Co16][Ki16][64]*/, const f32x4* __restrict__ Bv /*[Co16][64]*/,
+                                                       const f32x4* __restrict__ X, const f32x4* __restrict__ R /*residual or null*/,
+                                                       f32x4* __restrict__ Y, int n_tiles, int Ki16, int Co16, int taps, int relu /*1: before the residual add, 2: after*/) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n_tasks = (int64_t)n_tiles * CF_T;
+    for (int64_t task = (int64_t)blockIdx.x * 4 + wave; task < n_tasks; task += (int64_t)gridDim.x * 4) {
+        const int64_t tile = task / CF_T;
+        const int t = (int)(task - tile * CF_T);
+        for (int mo = 0; mo < Co16; mo += 2) {
+            const int m1 = mo + 1 < Co16 ? mo + 1 : mo;
+            f32x4 acc0 = Bv[mo * 64 + lane], acc1 = Bv[m1 * 64 + lane];
+            for (int tap = 0; tap < taps; ++tap) {
+                const int tt = t + tap - (taps >> 1);
+                if (tt < 0 || tt >= CF_T) continue;                           // zero padding at the window edges
+                const f32x4* xb = X + ((tile * CF_T + tt) * Ki16) * 64 + lane;
+                const f32x4* wa = W + ((int64_t)(tap * Co16 + mo) * Ki16) * 64 + lane;
+                const f32x4* wb = W + ((int64_t)(tap * Co16 + m1) * Ki16) * 64 + lane;
+#pragma unroll 2
+                for (int kb = 0; kb < Ki16; ++kb) {
+                    const f32x4 b = xb[kb * 64], a0 = wa[kb * 64], a1 = wb[kb * 64];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0 = MFMA16(a0[i], b[i], acc0);
+                        acc1 = MFMA16(a1[i], b[i], acc1);
+                    }
+                }
+            }
+            f32x4* y0 = Y + ((tile * CF_T + t) * Co16 + mo) * 64 + lane;
+            f32x4* y1 = Y + ((tile * CF_T + t) * Co16 + m1) * 64 + lane;
+            if (relu & 1) {                                                   // relu(BN(conv)), resnet_class.py:66,71,76
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc0[j] = fmaxf(acc0[j], 0.f); acc1[j] = fmaxf(acc1[j], 0.f); }
+            }
+            if (R) {                                                          // + shortcut, resnet_class.py:79
+                acc0 += R[((tile * CF_T + t) * Co16 + mo) * 64 + lane];
+                acc1 += R[((tile * CF_T + t) * Co16 + m1) * 64 + lane];
+            }
+            if (relu & 2) {                                                   // relu(o + shortcut), resnet_class.py:80
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc0[j] = fmaxf(acc0[j], 0.f); acc1[j] = fmaxf(acc1[j], 0.f); }
+            }
+            *y0 = acc0;
+            if (m1 != mo) *y1 = acc1;
+        }
+    }
+}
+
+// ---- one bidirectional GRU layer (rnn_class.py:142-148,165-175; GRUCell wiring of the checkpoint's graph) -----------------
+// One wave = one 16-window tile of one direction, 35 serial steps.  Per step: r = sigmoid(Wr [x, h] + br), two output tiles
+// at a time; then, per output tile, c = tanh(Wc [x, r.h] + bc) and u = sigmoid(Wu [x, h] + bu) side by side,
+// h' = u h + (1 - u) c.  The gate weights are pre-scaled for exp2 (CF_GATE_SCALE / CF_CAND_SCALE).  The three state arrays
+// of the wave live in LDS ([H16][64] f32x4 each); only this wave touches them, in program order.
+__global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ W /*[2 dirs][3: r, u, c][H16][KB][64]*/,
+                                                      const f32x4* __restrict__ Bv /*[2][3][H16][64]*/, const f32x4* __restrict__ X /*[tiles][35][KBX][64]*/,
+                                                      f32x4* __restrict__ Y /*[tiles][35][2 H16][64]*/, int n_tiles, int H16, int KBX) {
+    extern __shared__ f32x4 gen_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dir = blockIdx.y;
+    const int waves = blockDim.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * waves + wave;
+    if (tile >= n_tiles) return;                                  // no workgroup barrier anywhere in this kernel
+    const int KB = KBX + H16;
+    f32x4* hs = gen_lds + (size_t)wave * 3 * H16 * 64 + lane;
+    f32x4* rh = hs + (size_t)H16 * 64;
+    f32x4* cs = rh + (size_t)H16 * 64;
+    const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64 + lane;
+    const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64 + lane;
+    const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64 + lane;
+    const f32x4* Br = Bv + ((size_t)(dir * 3 + 0) * H16) * 64 + lane;
+    const f32x4* Bu = Bv + ((size_t)(dir * 3 + 1) * H16) * 64 + lane;
+    const f32x4* Bc = Bv + ((size_t)(dir * 3 + 2) * H16) * 64 + lane;
+    for (int mo = 0; mo < H16; ++mo) hs[mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f};       // GRUCellZeroState
+    for (int s = 0; s < CF_T; ++s) {
+        const int t = dir ? CF_T - 1 - s : s;                     // ReverseV2 around the backward direction
+        const f32x4* xt = X + ((tile * CF_T + t) * KBX) * 64 + lane;
+        // reset gate, then r.h (gru_cell/mul -> concat_1)
+        for (int mo = 0; mo < H16; mo += 2) {
+            const int m1 = mo + 1 < H16 ? mo + 1 : mo;
+            f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64];
+            const f32x4* wa = Wr + (size_t)mo * KB * 64;
+            const f32x4* wb = Wr + (size_t)m1 * KB * 64;
+#pragma unroll 2
+            for (int kb = 0; kb < KBX; ++kb) {
+                const f32x4 b = xt[kb * 64], a0 = wa[kb * 64], a1 = wb[kb * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc0 = MFMA16(a0[i], b[i], acc0); acc1 = MFMA16(a1[i], b[i], acc1); }
+            }
+#pragma unroll 2
+            for (int kb = 0; kb < H16; ++kb) {
+                const f32x4 b = hs[kb * 64], a0 = wa[(KBX + kb) * 64], a1 = wb[(KBX + kb) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc0 = MFMA16(a0[i], b[i], acc0); acc1 = MFMA16(a1[i], b[i], acc1); }
+            }
+            const f32x4 h0 = hs[mo * 64], h1 = hs[m1 * 64];
+            f32x4 r0, r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc0[j])) * h0[j];
+                r1[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc1[j])) * h1[j];
+            }
+            rh[mo * 64] = r0;
+            rh[m1 * 64] = r1;
+        }
+        // candidate and update gate of one output tile side by side; h' = u h + (1 - u) c (gru_cell/mul_1, sub, mul_2, add)
+        for (int mo = 0; mo < H16; ++mo) {
+            f32x4 accc = Bc[mo * 64], accu = Bu[mo * 64];
+            const f32x4* wc = Wc + (size_t)mo * KB * 64;
+            const f32x4* wu = Wu + (size_t)mo * KB * 64;
+#pragma unroll 2
+            for (int kb = 0; kb < KBX; ++kb) {
+                const f32x4 b = xt[kb * 64], a0 = wc[kb * 64], a1 = wu[kb * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { accc = MFMA16(a0[i], b[i], accc); accu = MFMA16(a1[i], b[i], accu); }
+            }
+#pragma unroll 2
+            for (int kb = 0; kb < H16; ++kb) {
+                const f32x4 bc = rh[kb * 64], bu = hs[kb * 64], a0 = wc[(KBX + kb) * 64], a1 = wu[(KBX + kb) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { accc = MFMA16(a0[i], bc[i], accc); accu = MFMA16(a1[i], bu[i], accu); }
+            }
+            const f32x4 h0 = hs[mo * 64];
+            f32x4 hn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accc[j])), 1.0f);
+                const float u = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accu[j]));
+                hn[j] = fmaf(u, h0[j] - c, c);
+            }
+            cs[mo * 64] = hn;
+            Y[((tile * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane] = hn;
+        }
+        f32x4* tmp = hs; hs = cs; cs = tmp;
+    }
+}
+
+// ---- dense 2H -> 1 + sigmoid (rnn_class.py:178-183, :84): one wave per (tile, position) ------------------------------------------
+__global__ __launch_bounds__(256) void gen_head_kernel(const f32x4* __restrict__ Y /*[tiles][35][F16][64]*/, const f32x4* __restrict__ dw /*[F16][64]*/,
+                                                       float bias, float* __restrict__ probs, float* __restrict__ logits, int64_t n_windows,
+                                                       int n_tiles, int F16) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n_tasks = (int64_t)n_tiles * CF_T;
+    for (int64_t task = (int64_t)blockIdx.x * 4 + wave; task < n_tasks; task += (int64_t)gridDim.x * 4) {
+        const int64_t tile = task / CF_T;
+        const int t = (int)(task - tile * CF_T);
+        const f32x4* y = Y + (task * F16) * 64 + lane;
+        float p = 0.f;
+        for (int mo = 0; mo < F16; ++mo) {
+            const f32x4 v = y[mo * 64], w = dw[mo * 64 + lane];
+            p = fmaf(v[0], w[0], p); p = fmaf(v[1], w[1], p); p = fmaf(v[2], w[2], p); p = fmaf(v[3], w[3], p);
+        }
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        const int64_t w = tile * CF_TILE + (lane & 15);
+        if (lane < 16 && w < n_windows) {
+            const float z = p + bias;
+            if (logits) logits[w * CF_T + t] = z;
+            if (probs) probs[w * CF_T + t] = 1.0f / (1.0f + __expf(-z));
+        }
+    }
+}
+
+// ---- host side: packing ---------------------------------------------------------------------------------------------------------
+struct cf_generic {
+    int C16 = 0, H16 = 0;                       // conv channels / 16 (0 = RNN type), GRU units / 16
+    struct Block { f32x4* w_sc = nullptr; f32x4* b_sc = nullptr; f32x4* w_1 = nullptr; f32x4* b_1 = nullptr;
+                   f32x4* w_3 = nullptr; f32x4* b_3 = nullptr; f32x4* w_l = nullptr; f32x4* b_l = nullptr; f32x4* first = nullptr; };
+    std::vector<Block> blocks;
+    struct Layer { f32x4* w = nullptr; f32x4* b = nullptr; int kbx = 0; };
+    std::vector<Layer> layers;
+    f32x4* dense = nullptr;
+    std::vector<void*> owned;                   // every device allocation above
+    float* r[4] = {nullptr, nullptr, nullptr, nullptr};      // conv activations, C features
+    float* g[2] = {nullptr, nullptr};                        // biGRU outputs, 2H features
+    int gru_waves = 8;
+    size_t gru_lds = 0;
+};
+
+// W(in, out) accessor -> A pack; inputs in >= k_real are zero padding
+template <typename F>
+static void gen_pack_a(std::vector<float>& dst, size_t off, F w, int k_real, int K16, int M16, double scale) {
+    for (int mo = 0; mo < M16; ++mo)
+        for (int kb = 0; kb < K16; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int in = 16 * kb + 4 * (lane >> 4) + i, out = 16 * mo + (lane & 15);
+                    dst[off + (((size_t)mo * K16 + kb) * 64 + lane) * 4 + i] = in < k_real ? (float)(w(in, out) * scale) : 0.f;
+                }
+}
+
+// per-output vector (bias, dense weights) in accumulator order: [mo][lane][j] = v[16 mo + 4 (lane >> 4) + j]
+template <typename F>
+static void gen_pack_v(std::vector<float>& dst, size_t off, F v, int M16, double scale) {
+    for (int mo = 0; mo < M16; ++mo)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) dst[off + ((size_t)mo * 64 + lane) * 4 + j] = (float)(v(16 * mo + 4 * (lane >> 4) + j) * scale);
+}

@@ -262,8 +262,16 @@ class Trainer(object):
         if seed is not None:
             self.gen.manual_seed(int(seed))
         self.last_loss = None
-        # native = the whole step on the HIP training kernels, no autograd (default on a GPU for the ResNetRNN type)
-        self.native = (self.net.device.type == "cuda" and n_layers_res > 0) if native is None else bool(native)
+        # native = the whole step on the HIP training kernels, no autograd: the default on a GPU for the ResNetRNN type at
+        # the shipped geometry (64 GRU units, 32 conv channels), which is what those kernels are specialised for.  Other
+        # draws of train_validate.generate_random_hyperparameters train on the torch-autograd restatement (PyTorch-ROCm on
+        # the same GPU); their inference runs on the any-size HIP path (csrc/generic.hpp) either way.
+        h = int(np.asarray(weights["stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/gru_cell/candidate/bias"]).shape[0])
+        c = int(np.asarray(weights["conv1d/bias"]).shape[0]) if n_layers_res > 0 else 32
+        shipped = (h == 64 and c == 32)
+        if native and not shipped:
+            raise ValueError("the native training kernels are built for layer_size = 64 and layer_size_res = 32")
+        self.native = (self.net.device.type == "cuda" and n_layers_res > 0 and shipped) if native is None else bool(native)
         self.engine = None
         self.step_impl = None
         if self.native:

@@ -205,6 +205,61 @@ def test_fused_single_launch_matches_per_layer_launches(ckpt_weights, n_windows)
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("h,c,n_layers,n_layers_res,n", [
+    (16, 16, 1, 1, 70), (32, 64, 2, 1, 333), (128, 16, 2, 2, 90), (256, 128, 1, 1, 40), (64, 256, 1, 2, 50),
+    (48, 80, 3, 3, 100), (32, 0, 2, 0, 200), (128, 0, 1, 0, 60), (64, 32, 5, 4, 64), (16, 32, 2, 2, 4500)])
+def test_any_size_models_match_oracle(h, c, n_layers, n_layers_res, n):
+    """The model classes accept any layer_size / layer_size_res (the reference's hyper-parameter search draws 16..256 and
+    1..5 / 1..11 layers, networks/train_validate.py:66-111); everything but the shipped 64 / 32 geometry runs on the
+    any-size kernels (csrc/generic.hpp).  Random glorot weights, ragged window counts, the plain RNN type (c = 0) included:
+    probabilities within 1e-4 of the fp64 oracle, logits consistent, batch-split invariant."""
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=100 + h + c, layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res)
+    rng = np.random.default_rng(h * 7 + c)
+    x = rng.normal(0, 1.3, size=(n, 35)).astype(np.float32)
+    eng = HipEngine(w, layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res, device=0,
+                    max_windows_per_pass=2048)
+    try:
+        assert eng.launch_regimes()["coop_max"] == 0 or (h == 64 and c in (0, 32))     # shipped geometry = tuned kernels
+        got, logits = eng.infer_host(x, return_logits=True)
+        m = min(n, 160)
+        want = oracle.forward(x[:m], w, np.float64, n_layers=n_layers, n_layers_res=n_layers_res)
+        assert got.shape == (n * 35,) and np.isfinite(got).all()
+        assert np.abs(got[:m * 35] - want).max() < TOL
+        assert np.abs(1.0 / (1.0 + np.exp(-logits.astype(np.float64))) - got).max() < 1e-6
+        if n > m:                       # the tail of a multi-pass call (2048-window passes) against the oracle too
+            want_t = oracle.forward(x[n - 40:], w, np.float64, n_layers=n_layers, n_layers_res=n_layers_res)
+            assert np.abs(got[(n - 40) * 35:] - want_t).max() < TOL
+        part = eng.infer_host(x[3:n // 2 + 1])
+        assert np.array_equal(part, got[3 * 35:(n // 2 + 1) * 35])
+        eng.check_error()
+    finally:
+        eng.close()
+
+
+def test_any_size_path_agrees_with_the_tuned_kernels_on_the_checkpoint(ckpt_weights, monkeypatch):
+    """CATFISH_GENERIC=1 sends the shipped geometry through the any-size kernels too: same checkpoint, same reads, the two
+    implementations agree to 2e-6 and both sit within 1e-4 of the fp64 oracle; bf16 is refused on that path."""
+    from catfish_amd.engine import HipEngine
+    x = np.random.default_rng(21).normal(0, 1.5, size=(354, 35)).astype(np.float32)
+    tuned = HipEngine(ckpt_weights, device=0, max_windows_per_pass=1024)
+    monkeypatch.setenv("CATFISH_GENERIC", "1")
+    try:
+        generic = HipEngine(ckpt_weights, device=0, max_windows_per_pass=1024)
+        with pytest.raises(ValueError):
+            HipEngine(ckpt_weights, device=0, max_windows_per_pass=1024, precision="bf16")
+    finally:
+        monkeypatch.delenv("CATFISH_GENERIC")
+    try:
+        assert generic.launch_regimes()["coop_max"] == 0 and tuned.launch_regimes()["coop_max"] > 0
+        a, b = tuned.infer_host(x), generic.infer_host(x)
+        want = oracle.forward(x[:118], ckpt_weights, np.float64)
+        assert np.abs(a - b).max() < 2e-6
+        assert np.abs(b[:118 * 35] - want).max() < TOL
+    finally:
+        tuned.close(); generic.close()
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_two_million_window_launch_index_arithmetic(ckpt_weights, precision):
