@@ -58,9 +58,9 @@ def generate_random_hyperparameters(network_type, learning_rate_min=-4, learning
     """networks/train_validate.py:66-111, draw for draw (numpy's global generator, same call order).
 
     Kept quirk: the reference stores ``n_layers`` under ``n_layers_res`` (:109) and discards its own draw.
-    The HIP kernels are specialised for ``layer_size`` 64 / ``layer_size_res`` 32 (any depth); other draws raise
-    ValueError when the model is built -- pass ``layer_size_list=[64]``, ``size_layers_res_list=[32]`` to search
-    the supported family.
+    Every draw builds: the shipped geometry (``layer_size`` 64 / ``layer_size_res`` 32, any depth) runs on the tuned HIP
+    kernels and trains natively; other sizes infer on the any-size HIP kernels (csrc/generic.hpp) and train on the
+    torch-autograd restatement on the same GPU.
     """
     learning_rate = 10 ** np.random.randint(learning_rate_min, learning_rate_max)
     optimizer = np.random.choice(list(optimizer_list))
@@ -299,8 +299,8 @@ def validate(network, squiggles, max_seq_length, file_path, validation_start="ra
 def main(argv):
     """networks/train_validate.py:298-360: ``network_type train_npz_dir n_training_examples validation_npz_dir
     max_validation_length [validation_start [max_number]]``.  The training "database" argument is a directory of NPZ
-    reads (the reference takes a ZODB file); hyper-parameters are the shipped network's (the reference's commented
-    block :318-321) unless CATFISH_RANDOM_SEARCH=1 asks for the random draw over the supported family."""
+    reads (the reference takes a ZODB file); hyper-parameters are a random draw as in the reference (:328) unless
+    CATFISH_SHIPPED_HPARAMS=1 asks for the shipped network's (the reference's commented block :329-332)."""
     if len(argv) < 6:
         raise ValueError("The following arguments should be provided in this order:\n" +
                          "\t-network type\n\t-path to training db" +
@@ -314,8 +314,8 @@ def main(argv):
     max_seq_length = int(argv[5])
     validation_start = int(argv[6]) if len(argv) >= 7 else "random"
     max_number = int(argv[7]) if len(argv) >= 8 else 856
-    if os.environ.get("CATFISH_RANDOM_SEARCH") == "1":
-        hpm_dict = generate_random_hyperparameters(network_type, layer_size_list=[64], size_layers_res_list=[32])
+    if os.environ.get("CATFISH_SHIPPED_HPARAMS") != "1":
+        hpm_dict = generate_random_hyperparameters(network_type)
     elif network_type == "RNN":
         hpm_dict = {"batch_size": 256, "optimizer_choice": "Adam", "learning_rate": 0.001, "layer_size": 64,
                     "n_layers": 3, "keep_prob": 0.8}

@@ -325,6 +325,40 @@ def test_train_save_load_infer_loop(hp, tmp_path, monkeypatch):
     loaded.engine.close(); net.engine.close()
 
 
+@pytest.mark.parametrize("network_type,hpm", [
+    ("ResNetRNN", dict(batch_size=64, optimizer_choice="Adam", learning_rate=0.001, layer_size=128, n_layers=2, keep_prob=0.7,
+                       layer_size_res=64, n_layers_res=2)),
+    ("RNN", dict(batch_size=64, optimizer_choice="RMSProp", learning_rate=0.001, layer_size=32, n_layers=1, keep_prob=0.8))])
+def test_other_hyperparameter_draws_train_save_load_infer(network_type, hpm, tmp_path, monkeypatch):
+    """A draw of the reference's hyper-parameter search other than the shipped geometry (networks/train_validate.py:66-111,
+    :328): build with save=True, train a few steps (torch-autograd restatement on the GPU; the native training kernels are
+    built for 64 / 32), checkpoint, load the model directory back with load_network and infer on the any-size HIP kernels:
+    same predictions as the trained object and as the oracle on the saved weights, and the loss went down."""
+    pytest.importorskip("torch")
+    from catfish_amd import neural_network, train_validate as tv, checkpoint
+    monkeypatch.chdir(tmp_path)
+    net = tv.build_model(network_type, save=True, **dict(hpm, train_seed=0))
+    net.initialize_network(seed=6)
+    assert net.engine.launch_regimes()["coop_max"] == 0                      # the any-size path
+    db = tv.synthetic_example_db(n_reads=2, read_len=12000, seed=3)
+    losses = []
+    for step in range(12):
+        data, labels, _ = db.get_training_set(64, ratio=2)
+        net.train_network(tv.reshape_input(data, 35, 1), tv.reshape_input(labels, 35, 1), step + 1)
+        losses.append(net.train_loss)
+    assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3])
+    net.save_network_to_model_path(12)
+    loaded = neural_network.load_network(network_type, net.model_path, checkpoint=12)
+    assert (loaded.layer_size, loaded.n_layers) == (hpm["layer_size"], hpm["n_layers"])
+    x = np.random.default_rng(0).normal(0, 1.2, size=(50, 35, 1))
+    got = loaded.infer(x)
+    assert np.array_equal(got, net.infer(x))
+    saved = checkpoint.read_inference_weights(os.path.join(net.model_path, "checkpoints"), "ckpnt-12")
+    want = oracle.forward(x, saved, np.float64, n_layers=hpm["n_layers"], n_layers_res=hpm.get("n_layers_res", 0))
+    assert np.abs(got - want).max() < 1e-4
+    loaded.engine.close(); net.engine.close()
+
+
 def test_plain_rnn_type_matches_oracle(hp):
     """build_model("RNN") (neural_network.py:17-18): 3 x biGRU directly on the raw window, no residual blocks."""
     from catfish_amd import neural_network
