@@ -12,6 +12,81 @@
 // W[in = 16 kb + 4 (lane >> 4) + i][out = 16 mo + (lane & 15)], i = 0..3: component i is the A operand of the MFMA whose B
 // operand is register i of input tile kb (lane quarter q of that register carries feature 16 kb + 4 q + i).
 
+// Two output tiles over one K sequence: acc0 += A0 . B0, acc1 += A1 . B1, K = [KBX blocks whose B operand comes from global
+// memory (xb) | H16 blocks whose B operands come from LDS (hb0 for acc0, hb1 for acc1)].  The A fragments stream from L2 and
+// the loop is software-pipelined through a ring of CF_GEN_DEPTH k-blocks: block k + DEPTH is requested right after block k's
+// eight MFMAs have been issued, i.e. DEPTH x 256 MFMA cycles ahead of its use.
+#ifndef CF_GEN_DEPTH
+#define CF_GEN_DEPTH 4
+#endif
+__device__ __forceinline__ void gen_dot(f32x4& acc0, f32x4& acc1, const f32x4* __restrict__ wa, const f32x4* __restrict__ wb,
+                                        const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+    constexpr int D = CF_GEN_DEPTH;
+    const int KB = KBX + H16;
+    f32x4 A0[D], A1[D], B0[D], B1[D];
+    auto fetch = [&](int j, int k) {
+        A0[j] = wa[k * 64];
+        A1[j] = wb[k * 64];
+        if (k < KBX) { B0[j] = xb[k * 64]; B1[j] = B0[j]; }
+        else { B0[j] = hb0[(k - KBX) * 64]; B1[j] = hb1[(k - KBX) * 64]; }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < KB) fetch(j, j);
+    for (int k0 = 0; k0 < KB; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = k0 + j;
+            if (k < KB) {
+                const f32x4 a0 = A0[j], a1 = A1[j], b0 = B0[j], b1 = B1[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = MFMA16(a0[i], b0[i], acc0);
+                    acc1 = MFMA16(a1[i], b1[i], acc1);
+                }
+                if (k + D < KB) fetch(j, k + D);
+            }
+        }
+    }
+}
+
+// The same with four output tiles (four independent MFMA chains): acc0, acc2 use B0 and acc1, acc3 use B1.
+__device__ __forceinline__ void gen_dot4(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
+                                         const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
+                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+    constexpr int D = CF_GEN_DEPTH;
+    const int KB = KBX + H16;
+    f32x4 A0[D], A1[D], A2[D], A3[D], B0[D], B1[D];
+    auto fetch = [&](int j, int k) {
+        A0[j] = w0[k * 64];
+        A1[j] = w1[k * 64];
+        A2[j] = w2[k * 64];
+        A3[j] = w3[k * 64];
+        if (k < KBX) { B0[j] = xb[k * 64]; B1[j] = B0[j]; }
+        else { B0[j] = hb0[(k - KBX) * 64]; B1[j] = hb1[(k - KBX) * 64]; }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < KB) fetch(j, j);
+    for (int k0 = 0; k0 < KB; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = k0 + j;
+            if (k < KB) {
+                const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j], b0 = B0[j], b1 = B1[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = MFMA16(a0[i], b0[i], acc0);
+                    acc1 = MFMA16(a1[i], b1[i], acc1);
+                    acc2 = MFMA16(a2[i], b0[i], acc2);
+                    acc3 = MFMA16(a3[i], b1[i], acc3);
+                }
+                if (k + D < KB) fetch(j, k + D);
+            }
+        }
+    }
+}
+
 // ---- block 0's two k = 1 convs on the raw sample (Cin = 1): shortcut and first conv, resnet_class.py:60-66 ---------------
 __global__ __launch_bounds__(256) void gen_first_kernel(const float* __restrict__ x_nat, const f32x4* __restrict__ wb /*[4][Co16][64]: w_sc, b_sc, w_1, b_1*/,
                                                         f32x4* __restrict__ SC, f32x4* __restrict__ O1, int64_t n_windows, int n_tiles, int Co16) {
@@ -56,15 +131,7 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__
                 const f32x4* xb = X + ((tile * CF_T + tt) * Ki16) * 64 + lane;
                 const f32x4* wa = W + ((int64_t)(tap * Co16 + mo) * Ki16) * 64 + lane;
                 const f32x4* wb = W + ((int64_t)(tap * Co16 + m1) * Ki16) * 64 + lane;
-#pragma unroll 2
-                for (int kb = 0; kb < Ki16; ++kb) {
-                    const f32x4 b = xb[kb * 64], a0 = wa[kb * 64], a1 = wb[kb * 64];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc0 = MFMA16(a0[i], b[i], acc0);
-                        acc1 = MFMA16(a1[i], b[i], acc1);
-                    }
-                }
+                gen_dot(acc0, acc1, wa, wb, xb, Ki16, nullptr, nullptr, 0);
             }
             f32x4* y0 = Y + ((tile * CF_T + t) * Co16 + mo) * 64 + lane;
             f32x4* y1 = Y + ((tile * CF_T + t) * Co16 + m1) * 64 + lane;
@@ -86,6 +153,10 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__
     }
 }
 
+#ifndef CF_GEN_LOCKSTEP
+#define CF_GEN_LOCKSTEP 1
+#endif
+
 // ---- one bidirectional GRU layer (rnn_class.py:142-148,165-175; GRUCell wiring of the checkpoint's graph) -----------------
 // One wave = one 16-window tile of one direction, 35 serial steps.  Per step: r = sigmoid(Wr [x, h] + br), two output tiles
 // at a time; then, per output tile, c = tanh(Wc [x, r.h] + bc) and u = sigmoid(Wu [x, h] + bu) side by side,
@@ -93,16 +164,22 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__
 // of the wave live in LDS ([H16][64] f32x4 each); only this wave touches them, in program order.
 __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ W /*[2 dirs][3: r, u, c][H16][KB][64]*/,
                                                       const f32x4* __restrict__ Bv /*[2][3][H16][64]*/, const f32x4* __restrict__ X /*[tiles][35][KBX][64]*/,
-                                                      f32x4* __restrict__ Y /*[tiles][35][2 H16][64]*/, int n_tiles, int H16, int KBX) {
+                                                      f32x4* Y /*[tiles][35][2 H16][64]*/, int H16, int KBX, int h_via_y) {
     extern __shared__ f32x4 gen_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dir = blockIdx.y;
     const int waves = blockDim.x >> 6;
+    // A workgroup's waves read the SAME weight stream; a barrier per output-tile group keeps them within one group of each
+    // other, so that the stream (24 KB per group at H = 64) is fetched from L2 once per CU and served to the other waves by
+    // the vector L1 (measured: see DESIGN.md, "Any-size path").  Waves past the last tile run on scratch tiles behind it (
+    // the host rounds the buffers up to whole workgroups of tiles).
     const int64_t tile = (int64_t)blockIdx.x * waves + wave;
-    if (tile >= n_tiles) return;                                  // no workgroup barrier anywhere in this kernel
     const int KB = KBX + H16;
-    f32x4* hs = gen_lds + (size_t)wave * 3 * H16 * 64 + lane;
+    // state: h and r.h always in LDS; h' in a third LDS array when eight waves' worth fits (H <= 64), otherwise it takes the
+    // round trip through the layer's output (written anyway) and is reloaded into the h array at the end of the step
+    const int arrays = h_via_y ? 2 : 3;
+    f32x4* hs = gen_lds + (size_t)wave * arrays * H16 * 64 + lane;
     f32x4* rh = hs + (size_t)H16 * 64;
-    f32x4* cs = rh + (size_t)H16 * 64;
+    f32x4* cs = rh + (size_t)H16 * 64;                            // only with three arrays
     const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64 + lane;
     const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64 + lane;
     const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64 + lane;
@@ -113,51 +190,34 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
     for (int s = 0; s < CF_T; ++s) {
         const int t = dir ? CF_T - 1 - s : s;                     // ReverseV2 around the backward direction
         const f32x4* xt = X + ((tile * CF_T + t) * KBX) * 64 + lane;
-        // reset gate, then r.h (gru_cell/mul -> concat_1)
-        for (int mo = 0; mo < H16; mo += 2) {
-            const int m1 = mo + 1 < H16 ? mo + 1 : mo;
-            f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64];
-            const f32x4* wa = Wr + (size_t)mo * KB * 64;
-            const f32x4* wb = Wr + (size_t)m1 * KB * 64;
-#pragma unroll 2
-            for (int kb = 0; kb < KBX; ++kb) {
-                const f32x4 b = xt[kb * 64], a0 = wa[kb * 64], a1 = wb[kb * 64];
+        // reset gate, then r.h (gru_cell/mul -> concat_1): four output tiles at a time (two when H < 64)
+        auto reset_tile = [&](int mo, const f32x4& acc) {
+            const f32x4 h0 = hs[mo * 64];
+            f32x4 r0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { acc0 = MFMA16(a0[i], b[i], acc0); acc1 = MFMA16(a1[i], b[i], acc1); }
-            }
-#pragma unroll 2
-            for (int kb = 0; kb < H16; ++kb) {
-                const f32x4 b = hs[kb * 64], a0 = wa[(KBX + kb) * 64], a1 = wb[(KBX + kb) * 64];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { acc0 = MFMA16(a0[i], b[i], acc0); acc1 = MFMA16(a1[i], b[i], acc1); }
-            }
-            const f32x4 h0 = hs[mo * 64], h1 = hs[m1 * 64];
-            f32x4 r0, r1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc0[j])) * h0[j];
-                r1[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc1[j])) * h1[j];
-            }
+            for (int j = 0; j < 4; ++j) r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[j])) * h0[j];
             rh[mo * 64] = r0;
-            rh[m1 * 64] = r1;
+        };
+        if (H16 >= 4) {
+            for (int mo = 0; mo < H16; mo += 4) {
+                const int m1 = mo + 1 < H16 ? mo + 1 : mo, m2 = mo + 2 < H16 ? mo + 2 : mo, m3 = mo + 3 < H16 ? mo + 3 : mo;
+                if (CF_GEN_LOCKSTEP) __syncthreads();
+                f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64], acc2 = Br[m2 * 64], acc3 = Br[m3 * 64];
+                gen_dot4(acc0, acc1, acc2, acc3, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, Wr + (size_t)m2 * KB * 64,
+                         Wr + (size_t)m3 * KB * 64, xt, KBX, hs, hs, H16);
+                reset_tile(mo, acc0); reset_tile(m1, acc1); reset_tile(m2, acc2); reset_tile(m3, acc3);
+            }
+        } else {
+            for (int mo = 0; mo < H16; mo += 2) {
+                const int m1 = mo + 1 < H16 ? mo + 1 : mo;
+                if (CF_GEN_LOCKSTEP) __syncthreads();
+                f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64];
+                gen_dot(acc0, acc1, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, xt, KBX, hs, hs, H16);
+                reset_tile(mo, acc0); reset_tile(m1, acc1);
+            }
         }
-        // candidate and update gate of one output tile side by side; h' = u h + (1 - u) c (gru_cell/mul_1, sub, mul_2, add)
-        for (int mo = 0; mo < H16; ++mo) {
-            f32x4 accc = Bc[mo * 64], accu = Bu[mo * 64];
-            const f32x4* wc = Wc + (size_t)mo * KB * 64;
-            const f32x4* wu = Wu + (size_t)mo * KB * 64;
-#pragma unroll 2
-            for (int kb = 0; kb < KBX; ++kb) {
-                const f32x4 b = xt[kb * 64], a0 = wc[kb * 64], a1 = wu[kb * 64];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { accc = MFMA16(a0[i], b[i], accc); accu = MFMA16(a1[i], b[i], accu); }
-            }
-#pragma unroll 2
-            for (int kb = 0; kb < H16; ++kb) {
-                const f32x4 bc = rh[kb * 64], bu = hs[kb * 64], a0 = wc[(KBX + kb) * 64], a1 = wu[(KBX + kb) * 64];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { accc = MFMA16(a0[i], bc[i], accc); accu = MFMA16(a1[i], bu[i], accu); }
-            }
+        // candidate and update gate side by side, two output tiles at a time; h' = u h + (1 - u) c (gru_cell/mul_1, sub, mul_2, add)
+        auto update_tile = [&](int mo, const f32x4& accc, const f32x4& accu) {
             const f32x4 h0 = hs[mo * 64];
             f32x4 hn;
 #pragma unroll
@@ -166,10 +226,30 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                 const float u = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accu[j]));
                 hn[j] = fmaf(u, h0[j] - c, c);
             }
-            cs[mo * 64] = hn;
+            if (!h_via_y) cs[mo * 64] = hn;
             Y[((tile * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane] = hn;
+        };
+        if (H16 >= 2) {
+            for (int mo = 0; mo < H16; mo += 2) {
+                const int m1 = mo + 1 < H16 ? mo + 1 : mo;
+                if (CF_GEN_LOCKSTEP) __syncthreads();
+                f32x4 c0 = Bc[mo * 64], u0 = Bu[mo * 64], c1 = Bc[m1 * 64], u1 = Bu[m1 * 64];
+                gen_dot4(c0, u0, c1, u1, Wc + (size_t)mo * KB * 64, Wu + (size_t)mo * KB * 64, Wc + (size_t)m1 * KB * 64,
+                         Wu + (size_t)m1 * KB * 64, xt, KBX, rh, hs, H16);
+                update_tile(mo, c0, u0);
+                if (m1 != mo) update_tile(m1, c1, u1);
+            }
+        } else {
+            if (CF_GEN_LOCKSTEP) __syncthreads();
+            f32x4 c0 = Bc[0], u0 = Bu[0];
+            gen_dot(c0, u0, Wc, Wu, xt, KBX, rh, hs, H16);
+            update_tile(0, c0, u0);
         }
-        f32x4* tmp = hs; hs = cs; cs = tmp;
+        if (h_via_y) {
+            for (int mo = 0; mo < H16; ++mo) hs[mo * 64] = Y[((tile * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane];
+        } else {
+            f32x4* tmp = hs; hs = cs; cs = tmp;
+        }
     }
 }
 
@@ -212,6 +292,7 @@ struct cf_generic {
     float* r[4] = {nullptr, nullptr, nullptr, nullptr};      // conv activations, C features
     float* g[2] = {nullptr, nullptr};                        // biGRU outputs, 2H features
     int gru_waves = 8;
+    bool h_via_y = false;
     size_t gru_lds = 0;
 };
 

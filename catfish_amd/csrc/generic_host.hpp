@@ -133,7 +133,8 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     cap = (cap + CF_TILE - 1) / CF_TILE * CF_TILE;
     m->cap_windows = cap;
     m->cap_tiles = cap / CF_TILE;
-    const size_t per_f16 = (size_t)m->cap_tiles * CF_T * 64 * sizeof(f32x4);           // bytes of one 16-feature tile plane
+    // (+ 8 tiles: the biGRU launch is whole workgroups of up to eight tiles; the waves past the last tile own scratch tiles)
+    const size_t per_f16 = (size_t)(m->cap_tiles + 8) * CF_T * 64 * sizeof(f32x4);     // bytes of one 16-feature tile plane
     const size_t r_bytes = per_f16 * std::max(1, g->C16), g_bytes = per_f16 * 2 * g->H16;
     const int n_r = g->C16 > 0 ? 4 : 1;
     for (int i = 0; i < n_r; ++i) {
@@ -148,8 +149,12 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     }
     m->ws_bytes = (int64_t)(n_r * r_bytes + 2 * g_bytes);
     // biGRU launch shape: the state of a tile takes 3 H 64 B of LDS; as many waves per workgroup as fit (8 at most)
-    const size_t per_wave = (size_t)3 * g->H16 * 64 * sizeof(f32x4);
-    g->gru_waves = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / per_wave));
+    // (h, r.h and h'); when eight waves of that do not fit, h' goes through the output buffer instead (two arrays) and the
+    // workgroup is 8 or 4 waves, so that every SIMD carries the same number
+    size_t per_wave = (size_t)3 * g->H16 * 64 * sizeof(f32x4);
+    g->h_via_y = per_wave * 8 > (size_t)(160 * 1024);
+    if (g->h_via_y) per_wave = (size_t)2 * g->H16 * 64 * sizeof(f32x4);
+    g->gru_waves = per_wave * 8 <= (size_t)(160 * 1024) ? 8 : 4;
     g->gru_lds = per_wave * g->gru_waves;
     HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru_lds));
     return CF_OK;
@@ -203,7 +208,7 @@ static int gen_run_pass(cf_model* m, const float* x, int64_t n_windows, float* p
         const int slot = l == 0 ? SLOT_GRU0 : (l + 1 == g->layers.size() ? SLOT_GRU_LAST : SLOT_GRU);
         if ((rc = prof_begin(m, slot, s, &pi)) != CF_OK) return rc;
         hipLaunchKernelGGL(gen_gru_kernel, dim3((unsigned)((n_tiles + g->gru_waves - 1) / g->gru_waves), 2), dim3(g->gru_waves * 64), g->gru_lds, s,
-                           L.w, L.b, cur, G[l & 1], n_tiles, g->H16, L.kbx);
+                           L.w, L.b, cur, G[l & 1], g->H16, L.kbx, g->h_via_y ? 1 : 0);
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
         cur = G[l & 1];
