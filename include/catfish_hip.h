@@ -46,7 +46,9 @@ extern "C" {
  * neural_network.retrieve_hyperparams (catfish/neural_network.py:37-67)
  * that shape the forward graph. */
 typedef struct cf_hparams {
-    int32_t layer_size;          /* GRU units per direction (rnn_class.py:16)        */
+    int32_t layer_size;          /* GRU units per direction (rnn_class.py:16): a multiple of 16, at most 256.
+                                    64 with layer_size_res 32 (the shipped checkpoint) runs on the tuned kernels,
+                                    every other geometry on the any-size kernels (fp32 only)            */
     int32_t n_layers;            /* stacked bidirectional layers (rnn_class.py:17)   */
     int32_t layer_size_res;      /* conv channels (resnet_class.py:11)               */
     int32_t n_layers_res;        /* residual blocks (resnet_class.py:10); 0 = RNN    */
