@@ -207,7 +207,9 @@ static int gen_run_pass(cf_model* m, const float* x, int64_t n_windows, float* p
         const cf_generic::Layer& L = g->layers[l];
         const int slot = l == 0 ? SLOT_GRU0 : (l + 1 == g->layers.size() ? SLOT_GRU_LAST : SLOT_GRU);
         if ((rc = prof_begin(m, slot, s, &pi)) != CF_OK) return rc;
-        hipLaunchKernelGGL(gen_gru_kernel, dim3((unsigned)((n_tiles + g->gru_waves - 1) / g->gru_waves), 2), dim3(g->gru_waves * 64), g->gru_lds, s,
+        // small calls (the reference's one-read-per-call pattern): fewer waves per workgroup, so that the tiles spread over the CUs
+        const int waves = std::max(1, std::min(g->gru_waves, (2 * n_tiles + m->n_cu - 1) / m->n_cu));
+        hipLaunchKernelGGL(gen_gru_kernel, dim3((unsigned)((n_tiles + waves - 1) / waves), 2), dim3(waves * 64), g->gru_lds / g->gru_waves * waves, s,
                            L.w, L.b, cur, G[l & 1], g->H16, L.kbx, g->h_via_y ? 1 : 0);
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
