@@ -42,6 +42,33 @@ def process_signal(fast5_file, normalization="median"):
     return normalize_raw_signal(_trimmed_fast5_signal(fast5_file), normalization)
 
 
+def _read_npy_int16(path):
+    """Fast path for the common case of a directory of reads: a version-1/2 ``.npy`` holding a one-dimensional C-order
+    little-endian int16 array, read with one ``read()`` and no literal_eval (np.load spends ~80 us per file in its
+    header parser, which bounds a rank at ~50 M samples/s).  Anything else returns None and goes through np.load."""
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if len(buf) < 12 or buf[:6] != b"\x93NUMPY" or buf[6] not in (1, 2):
+        return None
+    if buf[6] == 1:
+        hlen, off = int.from_bytes(buf[8:10], "little"), 10
+    else:
+        hlen, off = int.from_bytes(buf[8:12], "little"), 12
+    header = buf[off:off + hlen]
+    if b"'descr': '<i2'" not in header or b"'fortran_order': False" not in header:
+        return None
+    a, b = header.find(b"'shape': ("), header.find(b")", header.find(b"'shape': ("))
+    if a < 0 or b < 0:
+        return None
+    dims = [d for d in header[a + 10:b].split(b",") if d.strip()]
+    if len(dims) != 1 or not dims[0].strip().isdigit():
+        return None
+    n = int(dims[0])
+    if len(buf) != off + hlen + 2 * n:
+        return None
+    return np.frombuffer(buf, dtype="<i2", count=n, offset=off + hlen)
+
+
 def load_dac(path):
     """Raw samples of one read after the leader trim, NOT normalised (what the device ingest path uploads).
 
@@ -54,7 +81,9 @@ def load_dac(path):
         raise ValueError("path to FAST5 is not correct.")      # infer.py:25-26
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
-        raw = np.load(path, allow_pickle=False)
+        raw = _read_npy_int16(path)
+        if raw is None:
+            raw = np.load(path, allow_pickle=False)
     elif ext == ".npz":
         with np.load(path, allow_pickle=False) as z:
             raw = z["raw"] if "raw" in z.files else z["signal"]

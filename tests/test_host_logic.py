@@ -230,3 +230,34 @@ def test_quiet_gc_restores_the_collector():
         assert not gc.isenabled()
     finally:
         gc.enable() if was else gc.disable()
+
+
+def test_fast_npy_reader_matches_numpy(tmp_path):
+    """infer.load_dac's one-read() fast path for 1-D little-endian int16 .npy files (what a directory of DAC reads holds)
+    returns exactly np.load's array; every other layout (other dtype, 2-D, big-endian, Fortran order, empty, truncated)
+    takes the np.load route and gives what np.load gives."""
+    from catfish_amd import infer
+    rng = np.random.default_rng(3)
+    for n in (1, 35, 4096, 70001):
+        a = rng.integers(-32768, 32767, size=n).astype(np.int16)
+        p = str(tmp_path / ("r%d.npy" % n))
+        np.save(p, a)
+        assert infer._read_npy_int16(p) is not None
+        got = infer.load_dac(p)
+        assert got.dtype == np.int16 and np.array_equal(got, a)
+    odd = [np.arange(10, dtype=np.float32), np.arange(12, dtype=np.int16).reshape(3, 4), np.arange(5, dtype=">i2"),
+           np.asfortranarray(np.arange(6, dtype=np.int16).reshape(2, 3)), np.arange(9, dtype=np.int32)]
+    for i, a in enumerate(odd):
+        p = str(tmp_path / ("odd%d.npy" % i))
+        np.save(p, a)
+        assert infer._read_npy_int16(p) is None
+        assert np.array_equal(infer.load_dac(p), np.asarray(a).reshape(-1))
+    p = str(tmp_path / "trunc.npy")
+    np.save(p, np.arange(100, dtype=np.int16))
+    with open(p, "rb") as fh:
+        buf = fh.read()
+    with open(p, "wb") as fh:
+        fh.write(buf[:-10])
+    assert infer._read_npy_int16(p) is None            # the length check sends it to np.load, which reports the damage
+    with pytest.raises(Exception):
+        infer.load_dac(p)
