@@ -237,6 +237,20 @@ def test_any_size_models_match_oracle(h, c, n_layers, n_layers_res, n):
         eng.close()
 
 
+def test_unsupported_geometries_are_refused():
+    """Sizes the any-size kernels cannot tile (not a multiple of 16, above 256) and bf16 for a non-shipped geometry raise
+    ValueError with the library's message; nothing is allocated or left behind."""
+    from catfish_amd.engine import HipEngine
+    for kw in (dict(layer_size=24, layer_size_res=32), dict(layer_size=64, layer_size_res=40), dict(layer_size=272, layer_size_res=32),
+               dict(layer_size=8, layer_size_res=16)):
+        w = oracle.random_weights(seed=1, n_layers=1, n_layers_res=1, **kw)
+        with pytest.raises(ValueError, match="multiple of 16"):
+            HipEngine(w, n_layers=1, n_layers_res=1, device=0, max_windows_per_pass=64, **kw)
+    w = oracle.random_weights(seed=1, layer_size=128, layer_size_res=32, n_layers=1, n_layers_res=1)
+    with pytest.raises(ValueError, match="bf16"):
+        HipEngine(w, layer_size=128, layer_size_res=32, n_layers=1, n_layers_res=1, device=0, max_windows_per_pass=64, precision="bf16")
+
+
 def test_any_size_path_agrees_with_the_tuned_kernels_on_the_checkpoint(ckpt_weights, monkeypatch):
     """CATFISH_GENERIC=1 sends the shipped geometry through the any-size kernels too: same checkpoint, same reads, the two
     implementations agree to 2e-6 and both sit within 1e-4 of the fp64 oracle; bf16 is refused on that path."""
