@@ -14,7 +14,10 @@ def main():
     n = 256 * 118
     x = torch.randn(n, 35, device="cuda")
     out = torch.empty(n * 35, device="cuda")
-    for h, c, nl, nr in ((64, 32, 3, 2), (128, 64, 3, 2), (256, 128, 2, 2), (32, 64, 3, 2)):
+    geoms = ((64, 32, 3, 2), (128, 64, 3, 2), (256, 128, 2, 2), (32, 64, 3, 2))
+    if os.environ.get("GEN"):                       # one geometry "h,c,layers,blocks" (tools/pmc_generic.sh)
+        geoms = (tuple(int(v) for v in os.environ["GEN"].split(",")),)
+    for h, c, nl, nr in geoms:
         w = oracle.random_weights(seed=1, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr)
         os.environ["CATFISH_GENERIC"] = "1"
         eng = HipEngine(w, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr, device=0, max_windows_per_pass=n)
