@@ -261,3 +261,25 @@ def test_fast_npy_reader_matches_numpy(tmp_path):
     assert infer._read_npy_int16(p) is None            # the length check sends it to np.load, which reports the damage
     with pytest.raises(Exception):
         infer.load_dac(p)
+
+
+def test_missing_library_fails_loudly(hp):
+    """No CPU fallback: with the HIP library absent the product raises NativeLibraryMissing at the first use (model
+    restore, engine construction) -- it never routes around the kernels."""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            "from catfish_amd import _native, neural_network\n"
+            "try:\n"
+            "    _native.lib()\n"
+            "except _native.NativeLibraryMissing as e:\n"
+            "    print('LIB', type(e).__name__)\n"
+            "m = neural_network.build_model('ResNetRNN', **%r)\n"
+            "try:\n"
+            "    m.initialize_network(seed=0)\n"
+            "except _native.NativeLibraryMissing as e:\n"
+            "    print('MODEL', type(e).__name__)\n" % (dict(hp),))
+    env = dict(os.environ, CATFISH_HIP_LIB="/nonexistent/libcatfish_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "LIB NativeLibraryMissing" in out.stdout and "MODEL NativeLibraryMissing" in out.stdout
