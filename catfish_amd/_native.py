@@ -85,6 +85,10 @@ SYMBOLS = {
     "cf_gru_train_backward_dropout": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint32, C.c_int32,
                                                 C.c_void_p, C.c_void_p]),
+    "cf_gru_anysize_train_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int64, C.c_void_p]),
+    "cf_gru_anysize_train_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int64, C.c_void_p]),
     "cf_dropout_scale": (C.c_int, [C.c_void_p, C.c_float, C.c_uint32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cf_gru_wgrad_workspace_floats": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64]),
     "cf_gru_train_wgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

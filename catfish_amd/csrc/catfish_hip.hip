@@ -1894,6 +1894,64 @@ extern "C" int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpac
 
 // The mask / keep_prob tensor the training kernels apply to the output of `layer` (fragment layout [tiles][35][8][64][4]), written out
 // for tests and tools: the kernels themselves never store it.
+// ---- any-size biGRU layer for training (generic.hpp): forward with gate stash, backward chain -----------------------------------
+static int anysize_waves(int h16, int arrays, size_t* lds) {
+    const size_t per_wave = (size_t)arrays * h16 * 64 * sizeof(f32x4);
+    const int waves = per_wave * 8 <= (size_t)(160 * 1024) ? 8 : (per_wave * 4 <= (size_t)(160 * 1024) ? 4 : (per_wave * 2 <= (size_t)(160 * 1024) ? 2 : 1));
+    *lds = per_wave * waves;
+    return waves;
+}
+
+static int anysize_args_ok(const cf_model* m, int32_t layer_size, int64_t n_windows, const char* who) {
+    if (!m) return fail(CF_ERR_INVALID, std::string(who) + ": null model");
+    if (layer_size < 16 || layer_size > 256 || (layer_size % 16) != 0)
+        return fail(CF_ERR_INVALID, std::string(who) + ": layer_size must be a multiple of 16 between 16 and 256");
+    if (n_windows <= 0 || (n_windows % CF_TILE) != 0) return fail(CF_ERR_INVALID, std::string(who) + ": n_windows must be a positive multiple of 16");
+    return CF_OK;
+}
+
+extern "C" int cf_gru_anysize_train_forward(cf_model* m, int32_t layer_size, int32_t cin_blocks, const float* wpack, const float* bpack,
+                                            const float* x_frag, float* y_frag, float* stash, int64_t n_windows, void* stream) {
+    int rc = anysize_args_ok(m, layer_size, n_windows, "cf_gru_anysize_train_forward");
+    if (rc != CF_OK) return rc;
+    if (!wpack || !bpack || !x_frag || !y_frag || !stash) return fail(CF_ERR_INVALID, "cf_gru_anysize_train_forward: null buffer");
+    if (cin_blocks < 1 || cin_blocks > 32) return fail(CF_ERR_INVALID, "cf_gru_anysize_train_forward: cin_blocks must be 1..32 (input features / 16)");
+    HIP_TRY(hipSetDevice(m->device));
+    const int h16 = layer_size / 16, n_tiles = (int)(n_windows / CF_TILE);
+    size_t lds_full = 0;
+    int h_via_y = 0;
+    int max_waves = anysize_waves(h16, 3, &lds_full);
+    if (max_waves < 8) { h_via_y = 1; max_waves = anysize_waves(h16, 2, &lds_full); }     // as in the inference launch: h' through y above 64 units
+    const int waves = std::max(1, std::min(max_waves, (2 * n_tiles + m->n_cu - 1) / m->n_cu));
+    const size_t lds = lds_full / max_waves * waves;
+    HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(gen_gru_kernel<true>, dim3((unsigned)((n_tiles + waves - 1) / waves), 2), dim3(waves * 64), lds,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(wpack), reinterpret_cast<const f32x4*>(bpack),
+                       reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), h16, (int)cin_blocks, h_via_y,
+                       reinterpret_cast<f32x4*>(stash), n_tiles);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
+extern "C" int cf_gru_anysize_train_backward(cf_model* m, int32_t layer_size, const float* wtpack, const float* y_frag, const float* stash,
+                                             const float* dy_frag, float* da, int64_t n_windows, void* stream) {
+    int rc = anysize_args_ok(m, layer_size, n_windows, "cf_gru_anysize_train_backward");
+    if (rc != CF_OK) return rc;
+    if (!wtpack || !y_frag || !stash || !dy_frag || !da) return fail(CF_ERR_INVALID, "cf_gru_anysize_train_backward: null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const int h16 = layer_size / 16, n_tiles = (int)(n_windows / CF_TILE);
+    size_t lds = 0;
+    const int max_waves = anysize_waves(h16, 4, &lds);
+    const int waves = std::max(1, std::min(max_waves, (2 * n_tiles + m->n_cu - 1) / m->n_cu));
+    lds = lds / max_waves * waves;
+    HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(gen_gru_bwd_kernel, dim3((unsigned)((n_tiles + waves - 1) / waves), 2), dim3(waves * 64), lds,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(wtpack), reinterpret_cast<const f32x4*>(y_frag),
+                       reinterpret_cast<const f32x4*>(stash), reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<f32x4*>(da), n_tiles, h16);
+    HIP_TRY(hipGetLastError());
+    return CF_OK;
+}
+
 __global__ __launch_bounds__(256) void dropout_scale_kernel(f32x4* __restrict__ out, int64_t n4, cf_dropout drop) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) out[i] = cf_drop_scale4(cf_drop_key(drop), drop.keep_prob, i);

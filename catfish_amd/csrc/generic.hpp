@@ -162,9 +162,14 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__
 // at a time; then, per output tile, c = tanh(Wc [x, r.h] + bc) and u = sigmoid(Wu [x, h] + bu) side by side,
 // h' = u h + (1 - u) c.  The gate weights are pre-scaled for exp2 (CF_GATE_SCALE / CF_CAND_SCALE).  The three state arrays
 // of the wave live in LDS ([H16][64] f32x4 each); only this wave touches them, in program order.
+// TRAIN: the activated gates r, u, c of every step are stashed for the backward pass (S: [tiles][35][2 dirs][3][H16][64]), the
+// buffers are the caller's (exactly n_tiles tiles: waves past the last tile exit, so no workgroup barriers in this variant).
+template <bool TRAIN>
 __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ W /*[2 dirs][3: r, u, c][H16][KB][64]*/,
                                                       const f32x4* __restrict__ Bv /*[2][3][H16][64]*/, const f32x4* __restrict__ X /*[tiles][35][KBX][64]*/,
-                                                      f32x4* Y /*[tiles][35][2 H16][64]*/, int H16, int KBX, int h_via_y) {
+                                                      f32x4* Y /*[tiles][35][2 H16][64]*/, int H16, int KBX, int h_via_y, f32x4* __restrict__ S,
+                                                      int n_tiles) {
+    constexpr bool LOCKSTEP = CF_GEN_LOCKSTEP && !TRAIN;
     extern __shared__ f32x4 gen_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dir = blockIdx.y;
     const int waves = blockDim.x >> 6;
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
     // the vector L1 (measured: see DESIGN.md, "Any-size path").  Waves past the last tile run on scratch tiles behind it (
     // the host rounds the buffers up to whole workgroups of tiles).
     const int64_t tile = (int64_t)blockIdx.x * waves + wave;
+    if (TRAIN && tile >= n_tiles) return;
     const int KB = KBX + H16;
     // state: h and r.h always in LDS; h' in a third LDS array when eight waves' worth fits (H <= 64), otherwise it takes the
     // round trip through the layer's output (written anyway) and is reloaded into the h array at the end of the step
@@ -195,13 +201,14 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
             const f32x4 h0 = hs[mo * 64];
             f32x4 r0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[j])) * h0[j];
-            rh[mo * 64] = r0;
+            for (int j = 0; j < 4; ++j) r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[j]));
+            if (TRAIN) S[(((tile * CF_T + t) * 2 + dir) * 3 * H16 + mo) * 64 + lane] = r0;
+            rh[mo * 64] = r0 * h0;
         };
         if (H16 >= 4) {
             for (int mo = 0; mo < H16; mo += 4) {
                 const int m1 = mo + 1 < H16 ? mo + 1 : mo, m2 = mo + 2 < H16 ? mo + 2 : mo, m3 = mo + 3 < H16 ? mo + 3 : mo;
-                if (CF_GEN_LOCKSTEP) __syncthreads();
+                if (LOCKSTEP) __syncthreads();
                 f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64], acc2 = Br[m2 * 64], acc3 = Br[m3 * 64];
                 gen_dot4(acc0, acc1, acc2, acc3, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, Wr + (size_t)m2 * KB * 64,
                          Wr + (size_t)m3 * KB * 64, xt, KBX, hs, hs, H16);
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
         } else {
             for (int mo = 0; mo < H16; mo += 2) {
                 const int m1 = mo + 1 < H16 ? mo + 1 : mo;
-                if (CF_GEN_LOCKSTEP) __syncthreads();
+                if (LOCKSTEP) __syncthreads();
                 f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64];
                 gen_dot(acc0, acc1, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, xt, KBX, hs, hs, H16);
                 reset_tile(mo, acc0); reset_tile(m1, acc1);
@@ -219,12 +226,16 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
         // candidate and update gate side by side, two output tiles at a time; h' = u h + (1 - u) c (gru_cell/mul_1, sub, mul_2, add)
         auto update_tile = [&](int mo, const f32x4& accc, const f32x4& accu) {
             const f32x4 h0 = hs[mo * 64];
-            f32x4 hn;
+            f32x4 hn, cv, uv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float c = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accc[j])), 1.0f);
-                const float u = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accu[j]));
-                hn[j] = fmaf(u, h0[j] - c, c);
+                cv[j] = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accc[j])), 1.0f);
+                uv[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accu[j]));
+                hn[j] = fmaf(uv[j], h0[j] - cv[j], cv[j]);
+            }
+            if (TRAIN) {
+                S[(((tile * CF_T + t) * 2 + dir) * 3 * H16 + H16 + mo) * 64 + lane] = uv;
+                S[(((tile * CF_T + t) * 2 + dir) * 3 * H16 + 2 * H16 + mo) * 64 + lane] = cv;
             }
             if (!h_via_y) cs[mo * 64] = hn;
             Y[((tile * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane] = hn;
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
         if (H16 >= 2) {
             for (int mo = 0; mo < H16; mo += 2) {
                 const int m1 = mo + 1 < H16 ? mo + 1 : mo;
-                if (CF_GEN_LOCKSTEP) __syncthreads();
+                if (LOCKSTEP) __syncthreads();
                 f32x4 c0 = Bc[mo * 64], u0 = Bu[mo * 64], c1 = Bc[m1 * 64], u1 = Bu[m1 * 64];
                 gen_dot4(c0, u0, c1, u1, Wc + (size_t)mo * KB * 64, Wu + (size_t)mo * KB * 64, Wc + (size_t)m1 * KB * 64,
                          Wu + (size_t)m1 * KB * 64, xt, KBX, rh, hs, H16);
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                 if (m1 != mo) update_tile(m1, c1, u1);
             }
         } else {
-            if (CF_GEN_LOCKSTEP) __syncthreads();
+            if (LOCKSTEP) __syncthreads();
             f32x4 c0 = Bc[0], u0 = Bu[0];
             gen_dot(c0, u0, Wc, Wu, xt, KBX, rh, hs, H16);
             update_tile(0, c0, u0);
@@ -250,6 +261,88 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
         } else {
             f32x4* tmp = hs; hs = cs; cs = tmp;
         }
+    }
+}
+
+
+// Matrix-vector helper of the backward pass: out[mo] = sum_k W[mo][k] . B[k] for M16 output tiles (four at a time, two when
+// M16 < 4), B a K16-block array of this wave in LDS; epi(mo, acc) once per output tile.
+template <typename EP>
+__device__ __forceinline__ void gen_matvec(const f32x4* __restrict__ W /*lane-offset [M16][K16][64]*/, int M16, int K16, const f32x4* B, EP epi) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (M16 >= 4) {
+        for (int mo = 0; mo < M16; mo += 4) {
+            const int m1 = mo + 1 < M16 ? mo + 1 : mo, m2 = mo + 2 < M16 ? mo + 2 : mo, m3 = mo + 3 < M16 ? mo + 3 : mo;
+            f32x4 a0 = z, a1 = z, a2 = z, a3 = z;
+            gen_dot4(a0, a1, a2, a3, W + (size_t)mo * K16 * 64, W + (size_t)m1 * K16 * 64, W + (size_t)m2 * K16 * 64, W + (size_t)m3 * K16 * 64,
+                     nullptr, 0, B, B, K16);
+            epi(mo, a0);
+            if (mo + 1 < M16) epi(m1, a1);
+            if (mo + 2 < M16) epi(m2, a2);
+            if (mo + 3 < M16) epi(m3, a3);
+        }
+    } else {
+        for (int mo = 0; mo < M16; mo += 2) {
+            const int m1 = mo + 1 < M16 ? mo + 1 : mo;
+            f32x4 a0 = z, a1 = z;
+            gen_dot(a0, a1, W + (size_t)mo * K16 * 64, W + (size_t)m1 * K16 * 64, nullptr, 0, B, B, K16);
+            epi(mo, a0);
+            if (mo + 1 < M16) epi(m1, a1);
+        }
+    }
+}
+
+// ---- backward through time of one biGRU layer: the serial chain only ------------------------------------------------------------
+// Per step (reverse of the forward order), with h = the state BEFORE the step, dh = dL/dh' carried from the later step:
+//   dh' += dy;  du = dh' (h - c);  dc = dh' (1 - u);  dh = dh' u;  da_c = dc (1 - c^2);  da_u = du u (1 - u)
+//   d(r.h) = Wc_h^T da_c;  dr = d(r.h) h;  dh += d(r.h) r;  da_r = dr r (1 - r);  dh += Wg_h^T [da_r; da_u]
+// (rnn_class.py:142-148 differentiated; the graph's gradient nodes of the GRU cell).  Output: the pre-activation gradients
+// DA [tiles][35][2][3: r, u, c][H16][64]; the input gradient (W_x^T da) and the weight gradients ([x; h]^T da) are plain GEMMs
+// over all (window, step) pairs and are left to the caller.  WT: per direction Wc_h^T [H16][H16][64] then Wg_h^T [H16][2 H16][64],
+// A-fragment order, unscaled.
+__global__ __launch_bounds__(512) void gen_gru_bwd_kernel(const f32x4* __restrict__ WT, const f32x4* __restrict__ Y /*[tiles][35][2 H16][64]*/,
+                                                          const f32x4* __restrict__ S, const f32x4* __restrict__ DY /*[tiles][35][2 H16][64]*/,
+                                                          f32x4* __restrict__ DA, int n_tiles, int H16) {
+    extern __shared__ f32x4 gen_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dir = blockIdx.y;
+    const int waves = blockDim.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * waves + wave;
+    if (tile >= n_tiles) return;
+    f32x4* dh = gen_lds + (size_t)wave * 4 * H16 * 64 + lane;     // [dh][da_c][da_r][da_u], H16 blocks each; da_r, da_u adjacent
+    f32x4* dac = dh + (size_t)H16 * 64;
+    f32x4* dar = dac + (size_t)H16 * 64;
+    f32x4* dau = dar + (size_t)H16 * 64;
+    const f32x4* WcT = WT + ((size_t)dir * 3 * H16 * H16) * 64 + lane;
+    const f32x4* WgT = WcT + (size_t)H16 * H16 * 64;
+    for (int mo = 0; mo < H16; ++mo) dh[mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < CF_T; ++s) {
+        const int t = dir ? s : CF_T - 1 - s;                     // the forward pass ran 0..34 (dir 0) / 34..0 (dir 1)
+        const int tp = dir ? t + 1 : t - 1;                       // where the state before step t was written
+        const bool has_prev = tp >= 0 && tp < CF_T;
+        const f32x4* yp = Y + ((tile * CF_T + (has_prev ? tp : t)) * 2 * H16 + dir * H16) * 64 + lane;
+        const f32x4* st = S + (((tile * CF_T + t) * 2 + dir) * 3 * H16) * 64 + lane;
+        const f32x4* dy = DY + ((tile * CF_T + t) * 2 * H16 + dir * H16) * 64 + lane;
+        f32x4* da = DA + (((tile * CF_T + t) * 2 + dir) * 3 * H16) * 64 + lane;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int mo = 0; mo < H16; ++mo) {
+            const f32x4 hp = has_prev ? yp[mo * 64] : zero, u = st[(H16 + mo) * 64], c = st[(2 * H16 + mo) * 64];
+            const f32x4 dht = dy[mo * 64] + dh[mo * 64];
+            const f32x4 du = dht * (hp - c), dc = dht * (1.0f - u);
+            const f32x4 ac = dc * (1.0f - c * c), au = du * u * (1.0f - u);
+            dh[mo * 64] = dht * u;
+            dac[mo * 64] = ac;
+            dau[mo * 64] = au;
+            da[(2 * H16 + mo) * 64] = ac;
+            da[(H16 + mo) * 64] = au;
+        }
+        gen_matvec(WcT, H16, H16, dac, [&](int mo, const f32x4& drh) {
+            const f32x4 hp = has_prev ? yp[mo * 64] : zero, r = st[mo * 64];
+            const f32x4 ar = drh * hp * r * (1.0f - r);
+            dh[mo * 64] = dh[mo * 64] + drh * r;
+            dar[mo * 64] = ar;
+            da[mo * 64] = ar;
+        });
+        gen_matvec(WgT, H16, 2 * H16, dar, [&](int mo, const f32x4& g) { dh[mo * 64] = dh[mo * 64] + g; });
     }
 }
 

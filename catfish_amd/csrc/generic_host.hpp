@@ -156,7 +156,7 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     if (g->h_via_y) per_wave = (size_t)2 * g->H16 * 64 * sizeof(f32x4);
     g->gru_waves = per_wave * 8 <= (size_t)(160 * 1024) ? 8 : 4;
     g->gru_lds = per_wave * g->gru_waves;
-    HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru_lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru_lds));
     return CF_OK;
 }
 
@@ -209,8 +209,8 @@ static int gen_run_pass(cf_model* m, const float* x, int64_t n_windows, float* p
         if ((rc = prof_begin(m, slot, s, &pi)) != CF_OK) return rc;
         // small calls (the reference's one-read-per-call pattern): fewer waves per workgroup, so that the tiles spread over the CUs
         const int waves = std::max(1, std::min(g->gru_waves, (2 * n_tiles + m->n_cu - 1) / m->n_cu));
-        hipLaunchKernelGGL(gen_gru_kernel, dim3((unsigned)((n_tiles + waves - 1) / waves), 2), dim3(waves * 64), g->gru_lds / g->gru_waves * waves, s,
-                           L.w, L.b, cur, G[l & 1], g->H16, L.kbx, g->h_via_y ? 1 : 0);
+        hipLaunchKernelGGL(gen_gru_kernel<false>, dim3((unsigned)((n_tiles + waves - 1) / waves), 2), dim3(waves * 64), g->gru_lds / g->gru_waves * waves, s,
+                           L.w, L.b, cur, G[l & 1], g->H16, L.kbx, g->h_via_y ? 1 : 0, (f32x4*)nullptr, n_tiles);
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
         cur = G[l & 1];

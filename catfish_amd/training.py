@@ -68,6 +68,11 @@ class TorchResNetRNN(object):
         if x.dim() == 3:
             x = x[:, :, 0]
         a = x[:, None, :]                                # [N, C, T]
+        hsz0 = int(p["stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/gru_cell/candidate/bias"].shape[0])
+        csz0 = int(p["conv1d/bias"].shape[0]) if self.n_layers_res > 0 else 32
+        anysize = engine is not None and not (hsz0 == 64 and csz0 == 32)     # recurrence on the any-size HIP kernels
+        if anysize:
+            return self._logits_anysize(a, keep_prob, generator, engine, masks)
         native_res = engine is not None and self.n_layers_res > 0 and self.dtype == torch.float32
         if native_res:                                   # residual conv stack on the HIP training kernels
             from .native_train import native_res_stack, res_unit_names
@@ -116,6 +121,38 @@ class TorchResNetRNN(object):
             a = torch.cat(outs, 2)
         return (a.reshape(-1, a.shape[2]) @ p["final_fully_connected/kernel"] +
                 p["final_fully_connected/bias"]).reshape(n, t_len)
+
+    def _logits_anysize(self, a, keep_prob, generator, engine, masks):
+        """Any geometry other than 64 / 32: conv stack, dropout and head in torch, every biGRU layer one forward and one
+        backward launch of the any-size HIP kernels (catfish_amd/anysize_train.py)."""
+        torch = self.torch
+        p = self.params
+        from .anysize_train import anysize_bigru
+        for d in range(self.n_layers_res):
+            j0 = 4 * d
+            sc = self._conv_bn(a, j0)
+            o = torch.relu(self._conv_bn(a, j0 + 1))
+            o = torch.relu(self._conv_bn(o, j0 + 2))
+            o = torch.relu(self._conv_bn(o, j0 + 3))
+            a = torch.relu(o + sc)
+        a = a.permute(0, 2, 1).contiguous()              # [N, T, C]
+        n, t_len, _ = a.shape
+        pre = "stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/gru_cell"
+        for layer in range(self.n_layers):
+            params8 = [p[(pre % (layer, d)) + k] for d in ("fw", "bw")
+                       for k in ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")]
+            a = anysize_bigru(a, params8, engine)
+            if keep_prob < 1.0:                          # DropoutWrapper(output_keep_prob), one draw per direction as in the torch path
+                hsz = a.shape[2] // 2
+                parts = []
+                for dname in ("fw", "bw"):
+                    if masks is not None:
+                        parts.append(torch.as_tensor(masks[(layer, dname)], dtype=self.dtype, device=self.device))
+                    else:
+                        parts.append(torch.floor(keep_prob + torch.rand((n, t_len, hsz), generator=generator, device=self.device,
+                                                                        dtype=self.dtype)))
+                a = a / keep_prob * torch.cat(parts, 2)
+        return (a.reshape(-1, a.shape[2]) @ p["final_fully_connected/kernel"] + p["final_fully_connected/bias"]).reshape(n, t_len)
 
     def loss(self, x, y, keep_prob=1.0, generator=None, engine=None, masks=None):
         """tf.losses.sigmoid_cross_entropy + reduce_mean (rnn_class.py:74-79)."""
@@ -274,6 +311,13 @@ class Trainer(object):
         self.native = (self.net.device.type == "cuda" and n_layers_res > 0 and shipped) if native is None else bool(native)
         self.engine = None
         self.step_impl = None
+        # other geometries on a GPU: torch autograd around the any-size HIP recurrence kernels (anysize_train.py); the
+        # engine is only the C-ABI handle those launches go through.  native=False keeps pure torch (the test reference).
+        self.anysize = self.net.device.type == "cuda" and not shipped and native is None and self.net.dtype == torch.float32
+        if self.anysize:
+            from .engine import HipEngine
+            self.engine = HipEngine(weights, layer_size=h, n_layers=n_layers, layer_size_res=c, n_layers_res=n_layers_res,
+                                    device=self.net.device.index or 0, max_windows_per_pass=256)
         if self.native:
             from .engine import HipEngine
             self.engine = HipEngine(weights, n_layers=n_layers, n_layers_res=n_layers_res,

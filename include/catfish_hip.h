@@ -196,6 +196,21 @@ int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack, const flo
 int cf_gru_train_backward(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
                           const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
                           int64_t n_windows, void* stream);
+/* One biGRU layer of ANY geometry for training (layer_size a multiple of 16 up to 256; the reference's hyper-parameter search,
+ * networks/train_validate.py:66-111, draws 16..256).  These two run the serial part on the any-size kernels (csrc/generic.hpp);
+ * everything that is a plain GEMM over all (window, step) pairs -- the input gradient W_x^T da and the weight gradients
+ * [x; h]^T da -- is the caller's (catfish_amd/anysize_train.py uses library GEMMs).  Buffers are device pointers, fragment
+ * layout, n_windows a multiple of 16:
+ *   wpack   [2 dirs][3: r, u, c][H/16][cin_blocks + H/16][64][4]   A fragments, r / u scaled by -log2(e), c by 2 log2(e)
+ *   bpack   [2][3][H/16][64][4]                                    biases, same scaling
+ *   x_frag  [tiles][35][cin_blocks][64][4]    y_frag [tiles][35][2 H/16][64][4] (forward features first)
+ *   stash   [tiles][35][2][3: r, u, c][H/16][64][4]                 activated gates, written by the forward
+ *   wtpack  [2 dirs]{ Wc_h^T [H/16][H/16][64][4], Wg_h^T [H/16][2 H/16][64][4] }   unscaled
+ *   dy_frag like y_frag (dropout already applied by the caller); da like stash: dL/d(pre-activation) of r, u, c. */
+int cf_gru_anysize_train_forward(cf_model* m, int32_t layer_size, int32_t cin_blocks, const float* wpack, const float* bpack,
+                                 const float* x_frag, float* y_frag, float* stash, int64_t n_windows, void* stream);
+int cf_gru_anysize_train_backward(cf_model* m, int32_t layer_size, const float* wtpack, const float* y_frag, const float* stash,
+                                  const float* dy_frag, float* da, int64_t n_windows, void* stream);
 /* The same two calls with the layer's OUTPUT dropout (DropoutWrapper(output_keep_prob), rnn_class.py:151-154) done inside the
  * kernels, no mask tensor: whether an output element is kept is a hash of (seed, layer, *step_count, element index).  The
  * forward additionally writes y_drop_frag = y * mask / keep_prob (what the next layer or the dense head reads; y_frag itself stays

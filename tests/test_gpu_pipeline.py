@@ -458,6 +458,61 @@ def test_ultra_long_read_through_the_pipeline(model, tmp_path):
     model.engine.check_error()
 
 
+@pytest.mark.parametrize("h,c,n_layers,n_layers_res,n", [(32, 16, 2, 1, 40), (128, 64, 1, 1, 150), (48, 0, 2, 0, 75),
+                                                         (256, 32, 1, 1, 33), (16, 80, 3, 2, 600), (64, 64, 2, 1, 100)])
+def test_any_size_training_kernels_match_torch_autograd(h, c, n_layers, n_layers_res, n):
+    """cf_gru_anysize_train_forward / _backward (+ library GEMMs for dx and dW, catfish_amd/anysize_train.py) against torch
+    autograd of the restated graph at geometries other than 64 / 32: same loss, same gradient for every parameter, with
+    explicit output-dropout masks; ragged window counts, the plain RNN type and a multi-workgroup batch included."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.training import TorchResNetRNN
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=40 + h, layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res)
+    rng = np.random.default_rng(h + c)
+    x = rng.normal(0, 1.2, size=(n, 35)).astype(np.float32)
+    y = np.repeat((np.arange(n) % 2)[:, None], 35, axis=1).astype(np.float32)
+    masks = {(l, d): (rng.random((n, 35, h)) < 0.8).astype(np.float32) for l in range(n_layers) for d in ("fw", "bw")}
+    ref = TorchResNetRNN(w, n_layers, n_layers_res, device="cuda")
+    nat = TorchResNetRNN(w, n_layers, n_layers_res, device="cuda")
+    eng = HipEngine(w, layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res, device=0,
+                    max_windows_per_pass=256)
+    try:
+        l_ref = ref.loss(x, y, keep_prob=0.8, masks=masks)
+        l_ref.backward()
+        l_nat = nat.loss(x, y, keep_prob=0.8, engine=eng, masks=masks)
+        l_nat.backward()
+        assert abs(float(l_ref.detach()) - float(l_nat.detach())) < 1e-5
+        for k, p_ref in ref.trainable().items():
+            g_ref, g_nat = p_ref.grad, nat.trainable()[k].grad
+            assert g_nat is not None, k
+            scale = float(g_ref.abs().max()) + 1e-6
+            assert float((g_ref - g_nat).abs().max()) < 2e-4 * scale + 1e-6, (k, scale)
+    finally:
+        eng.close()
+
+
+def test_trainer_uses_the_any_size_kernels_for_other_geometries():
+    """Trainer on a 128 / 64 model: the recurrence runs on the any-size HIP kernels (trainer.anysize), ten Adam steps under
+    HIP-graph replay follow the pure-torch trainer's losses step for step, and the updated weights agree."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.training import Trainer
+    w = oracle.random_weights(seed=5, layer_size=128, n_layers=2, layer_size_res=64, n_layers_res=1)
+    rng = np.random.default_rng(0)
+    a = Trainer(w, 2, 1, "Adam", 1e-3, 1.0, seed=1)
+    b = Trainer(w, 2, 1, "Adam", 1e-3, 1.0, seed=1, native=False)
+    assert a.anysize and a.engine is not None and not a.native and not b.anysize
+    la, lb = [], []
+    for _ in range(10):
+        x = rng.normal(0, 1.0, size=(64, 35)).astype(np.float32)
+        y = np.repeat((rng.random(64) < 0.5)[:, None], 35, axis=1).astype(np.float32)
+        la.append(a.train_step(x, y))
+        lb.append(b.train_step(x, y))
+    assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
+    wa, wb = a.net.numpy_weights(), b.net.numpy_weights()
+    assert max(float(np.abs(wa[k] - wb[k]).max()) for k in wa) < 5e-5
+    a.engine.close()
+
+
 @pytest.mark.parametrize("n", [40, 2100])
 def test_native_gru_training_kernels_match_torch_autograd(n):
     """cf_gru_train_forward/backward (+ library GEMMs for dW) against torch autograd of the restated graph:
