@@ -59,8 +59,8 @@ def generate_random_hyperparameters(network_type, learning_rate_min=-4, learning
 
     Kept quirk: the reference stores ``n_layers`` under ``n_layers_res`` (:109) and discards its own draw.
     Every draw builds: the shipped geometry (``layer_size`` 64 / ``layer_size_res`` 32, any depth) runs on the tuned HIP
-    kernels and trains natively; other sizes infer on the any-size HIP kernels (csrc/generic.hpp) and train on the
-    torch-autograd restatement on the same GPU.
+    kernels and trains natively; other sizes infer on the any-size HIP kernels (csrc/generic.hpp) and train through torch
+    autograd with the recurrence on the same kernel family (anysize_train.py).
     """
     learning_rate = 10 ** np.random.randint(learning_rate_min, learning_rate_max)
     optimizer = np.random.choice(list(optimizer_list))

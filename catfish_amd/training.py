@@ -301,8 +301,8 @@ class Trainer(object):
         self.last_loss = None
         # native = the whole step on the HIP training kernels, no autograd: the default on a GPU for the ResNetRNN type at
         # the shipped geometry (64 GRU units, 32 conv channels), which is what those kernels are specialised for.  Other
-        # draws of train_validate.generate_random_hyperparameters train on the torch-autograd restatement (PyTorch-ROCm on
-        # the same GPU); their inference runs on the any-size HIP path (csrc/generic.hpp) either way.
+        # draws of train_validate.generate_random_hyperparameters train through torch autograd with the biGRU recurrence
+        # on the any-size HIP kernels (anysize_train.py); their inference runs on csrc/generic.hpp either way.
         h = int(np.asarray(weights["stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/gru_cell/candidate/bias"]).shape[0])
         c = int(np.asarray(weights["conv1d/bias"]).shape[0]) if n_layers_res > 0 else 32
         shipped = (h == 64 and c == 32)
