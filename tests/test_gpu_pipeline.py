@@ -331,8 +331,8 @@ def test_train_save_load_infer_loop(hp, tmp_path, monkeypatch):
     ("RNN", dict(batch_size=64, optimizer_choice="RMSProp", learning_rate=0.001, layer_size=32, n_layers=1, keep_prob=0.8))])
 def test_other_hyperparameter_draws_train_save_load_infer(network_type, hpm, tmp_path, monkeypatch):
     """A draw of the reference's hyper-parameter search other than the shipped geometry (networks/train_validate.py:66-111,
-    :328): build with save=True, train a few steps (torch-autograd restatement on the GPU; the native training kernels are
-    built for 64 / 32), checkpoint, load the model directory back with load_network and infer on the any-size HIP kernels:
+    :328): build with save=True, train a few steps (torch autograd around the any-size HIP recurrence kernels; the fully native
+    step is built for 64 / 32), checkpoint, load the model directory back with load_network and infer on the any-size HIP kernels:
     same predictions as the trained object and as the oracle on the saved weights, and the loss went down."""
     pytest.importorskip("torch")
     from catfish_amd import neural_network, train_validate as tv, checkpoint
@@ -492,8 +492,10 @@ def test_any_size_training_kernels_match_torch_autograd(h, c, n_layers, n_layers
 
 
 def test_trainer_uses_the_any_size_kernels_for_other_geometries():
-    """Trainer on a 128 / 64 model: the recurrence runs on the any-size HIP kernels (trainer.anysize), ten Adam steps under
-    HIP-graph replay follow the pure-torch trainer's losses step for step, and the updated weights agree."""
+    """Trainer on a 128 / 64 model: the recurrence runs on the any-size HIP kernels (trainer.anysize); the gradients of a
+    batch equal the pure-torch trainer's, and ten Adam steps under HIP-graph replay follow its loss trajectory (Adam
+    normalises the gradient, so rounding-level differences in near-zero gradients move individual weights by up to the
+    learning rate: the trajectory is compared, not the weights)."""
     torch = pytest.importorskip("torch")
     from catfish_amd.training import Trainer
     w = oracle.random_weights(seed=5, layer_size=128, n_layers=2, layer_size_res=64, n_layers_res=1)
@@ -501,15 +503,21 @@ def test_trainer_uses_the_any_size_kernels_for_other_geometries():
     a = Trainer(w, 2, 1, "Adam", 1e-3, 1.0, seed=1)
     b = Trainer(w, 2, 1, "Adam", 1e-3, 1.0, seed=1, native=False)
     assert a.anysize and a.engine is not None and not a.native and not b.anysize
+    x = rng.normal(0, 1.0, size=(64, 35)).astype(np.float32)
+    y = np.repeat((rng.random(64) < 0.5)[:, None], 35, axis=1).astype(np.float32)
+    la0, ga = a.gradients(x, y)
+    lb0, gb = b.gradients(x, y)
+    assert abs(la0 - lb0) < 1e-6
+    for k in gb:
+        assert np.abs(ga[k] - gb[k]).max() < 2e-4 * np.abs(gb[k]).max() + 1e-7, k
     la, lb = [], []
     for _ in range(10):
         x = rng.normal(0, 1.0, size=(64, 35)).astype(np.float32)
         y = np.repeat((rng.random(64) < 0.5)[:, None], 35, axis=1).astype(np.float32)
         la.append(a.train_step(x, y))
         lb.append(b.train_step(x, y))
-    assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
-    wa, wb = a.net.numpy_weights(), b.net.numpy_weights()
-    assert max(float(np.abs(wa[k] - wb[k]).max()) for k in wa) < 5e-5
+    assert np.isfinite(la).all() and np.allclose(la, lb, rtol=0, atol=2e-3), (la, lb)
+    assert la[-1] < la[0]
     a.engine.close()
 
 
@@ -570,7 +578,7 @@ def test_native_res_stack_training_kernels_match_torch_autograd(n, n_blocks):
         ref = a.permute(0, 2, 1)
         names = [k for unit in res_unit_names(n_blocks) for k in unit]
         got = native_res_stack(x, [net.params[k] for k in names], eng)
-        assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+        assert float((got - ref).detach().abs().max()) < 1e-5 * max(1.0, float(ref.detach().abs().max()))
         g = torch.randn_like(ref)
         train = [k for k in names if net.params[k].requires_grad]
         gr_ref = torch.autograd.grad((ref * g).sum(), [net.params[k] for k in train], retain_graph=True)
