@@ -34,4 +34,5 @@ rm -rf /tmp/kt_gen
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_gen -o kt -- python3 tools/bench_generic.py > $OUT/any_size_path.jsonl 2>/dev/null
 cp $(find /tmp/kt_gen -name "*kernel_stats.csv" | head -1) $OUT/any_size_kernel_stats.csv
 python tools/exp_generic_latency.py > $OUT/any_size_latency.jsonl 2>/dev/null
+python tools/bench_train_anysize.py > $OUT/any_size_training.jsonl 2>/dev/null
 echo "all done" >> $OUT/commit.txt
