@@ -359,6 +359,37 @@ def test_other_hyperparameter_draws_train_save_load_infer(network_type, hpm, tmp
     loaded.engine.close(); net.engine.close()
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("network_type,seed", [("ResNetRNN", 0), ("ResNetRNN", 3), ("RNN", 1), ("ResNetRNN", 11)])
+def test_train_validate_script_with_the_reference_default_random_draw(network_type, seed, tmp_path, monkeypatch):
+    """`python -m catfish_amd.train_validate <type> <train dir> <n> <val dir> <len> <start>` as the reference runs it
+    (networks/train_validate.py:299-347): hyper-parameters drawn at random (:328) -- whatever geometry comes up builds,
+    trains two batches, checkpoints, validates and writes both reports; the model directory loads back."""
+    pytest.importorskip("torch")
+    from catfish_amd import neural_network, train_validate as tv
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("CATFISH_SHIPPED_HPARAMS", raising=False)
+    (tmp_path / "train").mkdir()
+    (tmp_path / "val").mkdir()
+    for i in range(2):
+        raw, lab = tv.synthetic_labelled_read(30000, seed=70 + i)
+        np.savez(tmp_path / "train" / ("t%d.npz" % i), raw=raw, base_labels=lab)
+        raw, lab = tv.synthetic_labelled_read(3000, seed=80 + i)
+        np.savez(tmp_path / "val" / ("v%d.npz" % i), raw=raw, base_labels=lab)
+    np.random.seed(seed)
+    hpm = tv.generate_random_hyperparameters(network_type)                  # what main() is about to draw
+    np.random.seed(seed)
+    tv.main(["train_validate.py", network_type, str(tmp_path / "train"), str(2 * hpm["batch_size"]), str(tmp_path / "val"), "1050", "0"])
+    (model_dir,) = [d for d in tmp_path.iterdir() if d.is_dir() and d.name.endswith("_0")]      # <model type>_0, rnn_class.py:100-118
+    report = open(str(model_dir) + ".txt").read()
+    assert "layer_size: %d" % hpm["layer_size"] in report and "Saved checkpoint at step 2" in report
+    loaded = neural_network.load_network(network_type, str(model_dir), checkpoint=2)
+    assert loaded.layer_size == hpm["layer_size"] and loaded.n_layers == hpm["n_layers"]
+    out = loaded.infer(np.zeros((3, 35, 1)))
+    assert out.shape == (105,) and np.isfinite(out).all()
+    loaded.engine.close()
+
+
 def test_plain_rnn_type_matches_oracle(hp):
     """build_model("RNN") (neural_network.py:17-18): 3 x biGRU directly on the raw window, no residual blocks."""
     from catfish_amd import neural_network
