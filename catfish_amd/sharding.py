@@ -246,6 +246,34 @@ class EngineBatchRunner(object):
         return SpanTable(read_of, start, end, lengths)
 
 
+def _prefetched(gen, depth=3):
+    """Run a generator of read batches in a loader thread, ``depth`` batches ahead: file reads (which release the GIL)
+    and array assembly overlap the main thread's waits on the GPU.  Exceptions of the loader are re-raised here."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def loader():
+        try:
+            for item in gen:
+                q.put((item, None))
+            q.put((done, None))
+        except BaseException as exc:           # noqa: BLE001 -- handed to the consumer
+            q.put((done, exc))
+
+    t = threading.Thread(target=loader, name="catfish-loader", daemon=True)
+    t.start()
+    while True:
+        item, exc = q.get()
+        if item is done:
+            t.join()
+            if exc is not None:
+                raise exc
+            return
+        yield item
+
+
 def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_per_batch=None, batch_runner=None,
                         rank=None, world_size=None, gather_group=None, costs=None):
     """Homopolymer spans of many reads, sharded over the ranks of the job; rank 0 gets ``[(spans, length)]``
@@ -289,16 +317,17 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
                     tot += len(r)
                 if cur:
                     yield cur
+        source = _prefetched(batches(), depth=3) if load_fn is not None else batches()
         import torch.distributed as dist
         n_ranks = world_size if world_size is not None else (
             dist.get_world_size() if dist.is_available() and dist.is_initialized() else dist_env()[1])
         if isinstance(runner, EngineBatchRunner) and n_ranks > 1:
             # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
-            return SpanTable.concat(list(runner.run(batches(), compact=True)))
+            return SpanTable.concat(list(runner.run(source, compact=True)))
         # one rank: the per-read lists of batch k are built while the GPU runs batch k + 1 (0.3 ms per batch with the cyclic
         # collector off, see batching.quiet_gc)
         out = []
-        for res in runner.run(batches()):
+        for res in runner.run(source):
             out.extend(res)
         return out
 

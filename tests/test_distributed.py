@@ -176,3 +176,22 @@ def test_single_process_run_sharded_without_process_group():
     sigs = [np.zeros(n) for n in (10, 20, 30)]
     res = sharding.run_sharded(sigs, lambda b: [len(s) for s in b])
     assert res == [10, 20, 30]
+
+
+def test_prefetched_loader_keeps_order_and_raises():
+    """sharding._prefetched: batches come out in order from the loader thread; an exception inside the generator (a bad
+    file) surfaces in the consumer."""
+    from catfish_amd import sharding
+    assert list(sharding._prefetched(iter(range(50)), depth=3)) == list(range(50))
+    assert list(sharding._prefetched(iter(()), depth=2)) == []
+
+    def bad():
+        yield 1
+        yield 2
+        raise ValueError("path to FAST5 is not correct.")
+
+    got = []
+    with pytest.raises(ValueError, match="FAST5"):
+        for v in sharding._prefetched(bad(), depth=2):
+            got.append(v)
+    assert got == [1, 2]
