@@ -1769,7 +1769,8 @@ extern "C" int cf_gru_pack_map(int32_t cin, int32_t backward, int32_t* idx, floa
 
 static int train_cin_ok(const cf_model* m, int cin) {
     if (m->np != 0) return fail(CF_ERR_INVALID, "training kernels need a CF_PREC_FP32 model");
-    if (m->hp.layer_size != CF_H) return fail(CF_ERR_INVALID, "training kernels: layer_size 64 only (other sizes train on the torch-autograd path)");
+    if (m->hp.layer_size != CF_H) return fail(CF_ERR_INVALID, "training kernels: layer_size 64 only (other sizes: cf_gru_anysize_train_*)");
+    if (m->gen) return fail(CF_ERR_INVALID, "training kernels need a model on the tuned path (unset CATFISH_GENERIC)");
     if (cin != CF_C && cin != 2 * CF_H) return fail(CF_ERR_INVALID, "training kernels: cin must be 32 or 128");
     return CF_OK;
 }
@@ -2018,6 +2019,7 @@ extern "C" int cf_gru_train_wgrad(cf_model* m, int32_t cin, const float* x_frag,
 static int res_train_ok(const cf_model* m, int n_blocks) {
     if (n_blocks < 1 || 4 * n_blocks > RT_MAX_UNITS) return fail(CF_ERR_INVALID, "residual training kernels: 1..4 blocks");
     if (m->hp.layer_size_res != CF_C) return fail(CF_ERR_INVALID, "residual training kernels: 32 conv channels only");
+    if (m->gen) return fail(CF_ERR_INVALID, "residual training kernels need a model on the tuned path (unset CATFISH_GENERIC)");
     return CF_OK;
 }
 
