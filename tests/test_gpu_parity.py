@@ -237,6 +237,31 @@ def test_any_size_models_match_oracle(h, c, n_layers, n_layers_res, n):
         eng.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+def test_random_call_sizes_and_offsets_are_bit_identical(ckpt_weights, precision):
+    """Differential fuzz over the launch regimes (hoisted / cooperative / throughput / multi-pass): 80 seeded calls of
+    log-uniform size 1..40 000 windows at random offsets into one fixed input must reproduce, bit for bit, the
+    corresponding slice of a single 40 000-window call -- a window's result may not depend on the call it travels in."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd.engine import HipEngine
+    n_all = 40000
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=32768, precision=precision)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(11)
+        x = torch.randn(n_all, 35, generator=g).mul_(1.4).cuda()
+        full = eng.infer_device(x).view(n_all, 35).clone()
+        rng = np.random.default_rng(12)
+        sizes = np.unique(np.concatenate([np.exp(rng.uniform(0, np.log(n_all), size=72)).astype(int), [1, 15, 16, 17, 32768, 32769, n_all, 4097]]))
+        for n in sizes:
+            n = int(min(max(n, 1), n_all))
+            o = int(rng.integers(0, n_all - n + 1))
+            got = eng.infer_device(x[o:o + n].contiguous()).view(n, 35)
+            assert torch.equal(got, full[o:o + n]), (precision, n, o)
+        eng.check_error()
+    finally:
+        eng.close()
+
+
 def test_unsupported_geometries_are_refused():
     """Sizes the any-size kernels cannot tile (not a multiple of 16, above 256) and bf16 for a non-shipped geometry raise
     ValueError with the library's message; nothing is allocated or left behind."""
