@@ -42,6 +42,7 @@ __device__ __forceinline__ void gru_tile_coop(float* lds, float* xch, int lane, 
     const f32x4* WX = reinterpret_cast<const f32x4*>(lds) + lane;
     const f32x4* WG = WX + XN4;
     const f32x4* WC = WG + HG4;       // (far_lds measured 1 % slower here: the step is latency-, not issue-bound)
+    (void)WC;
     const f32x4* B4 = reinterpret_cast<const f32x4*>(lds + BIAS) + q;
     f32x4* hx = reinterpret_cast<f32x4*>(xch) + lane;              // [4 M-tiles][64 lanes] f32x4: the state h
     f32x4* rx = hx + 4 * 64;                                        // r * h

@@ -5,7 +5,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 
 from catfish_amd.engine import HipEngine
