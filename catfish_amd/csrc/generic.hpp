@@ -257,6 +257,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
             update_tile(0, c0, u0);
         }
         if (h_via_y) {
+            __builtin_amdgcn_s_waitcnt(0);                         // this wave's stores of h' have been acknowledged before it reads them back
             for (int mo = 0; mo < H16; ++mo) hs[mo * 64] = Y[((tile * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane];
         } else {
             f32x4* tmp = hs; hs = cs; cs = tmp;
