@@ -145,11 +145,20 @@ def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group
     n_items = len(costs)
     shards = shard_costs(costs, world_size)
     mine = shards[rank]
-    local = work_fn(mine) if mine else []
-    if not isinstance(local, SpanTable):
-        local = list(local)
-    if len(local) != len(mine):
-        raise RuntimeError("work_fn returned %d results for %d items" % (len(local), len(mine)))
+    # A rank whose shard fails (unreadable file, device error) must still reach the gather, or the others would wait
+    # for it until the process group times out: its error text travels in place of its results and every rank raises.
+    failure = None
+    local = []
+    try:
+        local = work_fn(mine) if mine else []
+        if not isinstance(local, SpanTable):
+            local = list(local)
+        if len(local) != len(mine):
+            raise RuntimeError("work_fn returned %d results for %d items" % (len(local), len(mine)))
+    except Exception as exc:          # noqa: BLE001 -- re-raised below, after the collective
+        if world_size == 1 or not distributed:
+            raise
+        failure = exc
 
     def place(out, idx, res):
         for i, r in zip(idx, res.expand() if isinstance(res, SpanTable) else res):
@@ -162,7 +171,17 @@ def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group
     if not distributed:
         raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group")
     gathered = [None] * world_size if rank == 0 else None
-    dist.gather_object((mine, local), gathered, dst=0, group=gather_group)     # a SpanTable travels as four arrays
+    payload = (mine, local) if failure is None else ("error", "%s: %s" % (type(failure).__name__, failure))
+    dist.gather_object(payload, gathered, dst=0, group=gather_group)            # a SpanTable travels as four arrays
+    verdict = [None]
+    if rank == 0:
+        bad = ["rank %d: %s" % (r, g[1]) for r, g in enumerate(gathered) if isinstance(g[0], str) and g[0] == "error"]
+        verdict[0] = "; ".join(bad) if bad else ""
+    dist.broadcast_object_list(verdict, src=0, group=gather_group)              # every rank learns whether the job failed
+    if failure is not None:
+        raise failure
+    if verdict[0]:
+        raise RuntimeError("sharded run failed on " + verdict[0])
     if rank != 0:
         return None
     out = [None] * n_items

@@ -195,3 +195,40 @@ def test_prefetched_loader_keeps_order_and_raises():
         for v in sharding._prefetched(bad(), depth=2):
             got.append(v)
     assert got == [1, 2]
+
+
+def _failing_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from catfish_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def work(mine):
+            if rank == 1:
+                raise ValueError("path to FAST5 is not correct.")          # what a missing file raises (infer.py:25-26)
+            return [("ok", i) for i in mine]
+
+        try:
+            sharding.run_sharded_indexed([1] * 10, work)
+            outcome = "returned"
+        except ValueError as exc:
+            outcome = "ValueError %s" % exc
+        except RuntimeError as exc:
+            outcome = "RuntimeError %s" % exc
+        open(os.path.join(tmpdir, "rank%d" % rank), "w").write(outcome)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_a_failing_rank_fails_the_whole_sharded_run_without_hanging(tmp_path):
+    """One rank's shard raises (a missing file): it still takes part in the gather, so nobody waits for it until the group
+    times out; the failing rank re-raises its own error, the others raise a RuntimeError that names it."""
+    import torch.multiprocessing as mp
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (tmp_path / "rank0").read_text(), (tmp_path / "rank1").read_text()
+    assert r1.startswith("ValueError") and "FAST5" in r1
+    assert r0.startswith("RuntimeError") and "rank 1" in r0 and "FAST5" in r0
