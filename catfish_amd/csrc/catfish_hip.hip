@@ -1335,8 +1335,6 @@ static int prof_end(cf_model* m, hipStream_t s, size_t idx) {
 // Waves per workgroup: 8 (two per SIMD) when the pass fills the chip; fewer for small calls (a single read is
 // 8 tiles x 2 directions) so that the tiles spread over more CUs instead of sharing SIMDs -- the 35-step
 // chain is latency-bound there.
-#include "generic_host.hpp"
-
 static int pick_waves(int n_tile_tasks, int n_cu) {
     int w = (n_tile_tasks + n_cu - 1) / n_cu;
     return w <= 1 ? 1 : (w <= 2 ? 2 : (w <= 4 ? 4 : 8));
@@ -1424,6 +1422,8 @@ static int launch_gru_bf16_layer(cf_model* m, int l, bool last, const float* cur
 }
 
 // fuse_layers = auto: the dynamically scheduled single launch pays from ~6 full-chip rounds of 8-tile groups per pass
+#include "generic_host.hpp"
+
 static int cf_fuse_min_groups(int n_cu) { return 6 * std::max(1, n_cu / 2); }
 
 static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_windows, float* probs, float* logits, hipStream_t s) {

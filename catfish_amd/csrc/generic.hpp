@@ -379,7 +379,8 @@ struct cf_generic {
     struct Block { f32x4* w_sc = nullptr; f32x4* b_sc = nullptr; f32x4* w_1 = nullptr; f32x4* b_1 = nullptr;
                    f32x4* w_3 = nullptr; f32x4* b_3 = nullptr; f32x4* w_l = nullptr; f32x4* b_l = nullptr; f32x4* first = nullptr; };
     std::vector<Block> blocks;
-    struct Layer { f32x4* w = nullptr; f32x4* b = nullptr; int kbx = 0; };
+    struct Layer { f32x4* w = nullptr; f32x4* b = nullptr; int kbx = 0;
+                   float* tuned = nullptr; int tuned_cin = 0; };     // 64 units and 16 / 32 / 128 inputs: the LDS-resident kernel's pack
     std::vector<Layer> layers;
     f32x4* dense = nullptr;
     std::vector<void*> owned;                   // every device allocation above

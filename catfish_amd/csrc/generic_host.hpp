@@ -2,9 +2,10 @@
 // Included by catfish_hip.hip after cf_model, fail(), HIP_TRY, prof_begin / prof_end.
 #pragma once
 
+static bool gen_forced() { return getenv("CATFISH_GENERIC") && atoi(getenv("CATFISH_GENERIC")) != 0; }     // A/B and test knob, read per model
+
 static bool gen_wanted(const cf_hparams* hp) {
-    const int force = getenv("CATFISH_GENERIC") ? atoi(getenv("CATFISH_GENERIC")) : 0;     // A/B and test knob, read per model
-    return force != 0 || hp->layer_size != CF_H || (hp->n_layers_res > 0 && hp->layer_size_res != CF_C);
+    return gen_forced() || hp->layer_size != CF_H || (hp->n_layers_res > 0 && hp->layer_size_res != CF_C);
 }
 
 static void gen_destroy(cf_generic* g) {
@@ -120,6 +121,17 @@ static int gen_build(cf_model* m, const cf_weights* w) {
         L.kbx = kbx;
         rc = gen_upload(g, wp, &L.w);
         if (rc == CF_OK) rc = gen_upload(g, bp, &L.b);
+        // 64 units with 16, 32 or 128 input features is what gru_layer_kernel<CIN, false> (weights in LDS, state in registers,
+        // 0.78-0.83 of the fp32-MFMA peak) is built for: such layers of an otherwise odd geometry (say 64 units behind 128
+        // conv channels) run on it.  Not when CATFISH_GENERIC forces this path: that knob exists to exercise the kernels here.
+        if (rc == CF_OK && H == CF_H && !gen_forced() && (cin_real == 16 || cin_real == 32 || cin_real == 128)) {
+            std::vector<float> blob((size_t)2 * gru_pack_floats(cin_real));
+            for (int d = 0; d < 2; ++d) pack_gru_dir(w->gru[2 * l + d], cin_real, cin_real, nullptr, blob.data() + (size_t)d * gru_pack_floats(cin_real));
+            f32x4* dev = nullptr;
+            rc = gen_upload(g, blob, &dev);
+            L.tuned = reinterpret_cast<float*>(dev);
+            L.tuned_cin = cin_real;
+        }
         g->layers.push_back(L);
     }
     if (rc == CF_OK) {
@@ -157,6 +169,12 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     g->gru_waves = per_wave * 8 <= (size_t)(160 * 1024) ? 8 : 4;
     g->gru_lds = per_wave * g->gru_waves;
     HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru_lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gru_pack_floats(16) * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gru_pack_floats(32) * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gru_pack_floats(128) * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_coop_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (gru_pack_floats(16) + CF_COOP_XCH_FLOATS) * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_coop_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_coop_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4));
     return CF_OK;
 }
 
@@ -206,6 +224,16 @@ static int gen_run_pass(cf_model* m, const float* x, int64_t n_windows, float* p
     for (size_t l = 0; l < g->layers.size(); ++l) {
         const cf_generic::Layer& L = g->layers[l];
         const int slot = l == 0 ? SLOT_GRU0 : (l + 1 == g->layers.size() ? SLOT_GRU_LAST : SLOT_GRU);
+        if (L.tuned) {               // a 64-unit layer with 16 / 32 / 128 inputs: the LDS-resident kernel (all its launch regimes)
+            const float* x_in = reinterpret_cast<const float*>(cur);
+            float* y_out = reinterpret_cast<float*>(G[l & 1]);
+            rc = L.tuned_cin == 16 ? launch_gru<16, false>(m, L.tuned, x_in, y_out, nullptr, n_tiles, s, slot)
+               : L.tuned_cin == 32 ? launch_gru<32, false>(m, L.tuned, x_in, y_out, nullptr, n_tiles, s, slot)
+                                   : launch_gru<128, false>(m, L.tuned, x_in, y_out, nullptr, n_tiles, s, slot);
+            if (rc != CF_OK) return rc;
+            cur = G[l & 1];
+            continue;
+        }
         if ((rc = prof_begin(m, slot, s, &pi)) != CF_OK) return rc;
         // small calls (the reference's one-read-per-call pattern): fewer waves per workgroup, so that the tiles spread over the CUs
         const int waves = std::max(1, std::min(g->gru_waves, (2 * n_tiles + m->n_cu - 1) / m->n_cu));

@@ -30,7 +30,7 @@ def main():
     n = 256 * 118
     x = torch.randn(n, 35, device="cuda")
     out = torch.empty(n * 35, device="cuda")
-    for h, c, nl, nr, force in ((64, 32, 3, 2, False), (64, 32, 3, 2, True), (16, 16, 2, 2, False), (32, 64, 3, 2, False),
+    for h, c, nl, nr, force in ((64, 32, 3, 2, False), (64, 32, 3, 2, True), (64, 64, 3, 2, False), (64, 128, 3, 2, False), (16, 16, 2, 2, False), (32, 64, 3, 2, False),
                                 (128, 64, 3, 2, False), (128, 128, 2, 4, False), (256, 128, 3, 2, False), (256, 256, 5, 5, False)):
         w = oracle.random_weights(seed=1, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr)
         if force:
