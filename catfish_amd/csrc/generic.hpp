@@ -51,8 +51,8 @@ __device__ __forceinline__ void gen_dot(f32x4& acc0, f32x4& acc1, const f32x4* _
 }
 
 // The same with four output tiles (four independent MFMA chains): acc0, acc2 use B0 and acc1, acc3 use B1.
-__device__ __forceinline__ void gen_dot4(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
-                                         const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
+__device__ __forceinline__ void gen_dot4_any(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
+                                             const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
                                          const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
     constexpr int D = CF_GEN_DEPTH;
     const int KB = KBX + H16;
@@ -85,6 +85,70 @@ __device__ __forceinline__ void gen_dot4(f32x4& acc0, f32x4& acc1, f32x4& acc2, 
             }
         }
     }
+}
+
+// Branch-free variant for segment lengths that are multiples of the ring depth (64 or more units / channels): no condition
+// depends on k -- ring refills and the one-ahead B loads clamp their index instead (a few redundant loads at the tail) -- so
+// the compiler can keep the whole ring in flight (with per-slot conditions it falls back to waiting for nearly every load:
+// vmcnt(0..5) in the ISA, and the matrix pipe was busy 51 % of the time).
+__device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
+                                              const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
+                                              const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+    constexpr int D = CF_GEN_DEPTH;
+    const int KB = KBX + H16, last = KB - 1;
+    f32x4 A0[D], A1[D], A2[D], A3[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { A0[j] = w0[j * 64]; A1[j] = w1[j * 64]; A2[j] = w2[j * 64]; A3[j] = w3[j * 64]; }
+    if (KBX > 0) {
+        f32x4 b = xb[0];
+        for (int k0 = 0; k0 < KBX; k0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const int k = k0 + j;
+                const int kn = k + 1 < KBX ? k + 1 : KBX - 1, kr = k + D < last ? k + D : last;
+                const f32x4 bn = xb[kn * 64];
+                const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = MFMA16(a0[i], b[i], acc0);
+                    acc1 = MFMA16(a1[i], b[i], acc1);
+                    acc2 = MFMA16(a2[i], b[i], acc2);
+                    acc3 = MFMA16(a3[i], b[i], acc3);
+                }
+                A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64];
+                b = bn;
+            }
+        }
+    }
+    if (H16 == 0) return;
+    f32x4 b0 = hb0[0], b1 = hb1[0];
+    for (int k0 = 0; k0 < H16; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int kh = k0 + j, k = KBX + kh;
+            const int kn = kh + 1 < H16 ? kh + 1 : H16 - 1, kr = k + D < last ? k + D : last;
+            const f32x4 n0 = hb0[kn * 64], n1 = hb1[kn * 64];
+            const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc0 = MFMA16(a0[i], b0[i], acc0);
+                acc1 = MFMA16(a1[i], b1[i], acc1);
+                acc2 = MFMA16(a2[i], b0[i], acc2);
+                acc3 = MFMA16(a3[i], b1[i], acc3);
+            }
+            A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64];
+            b0 = n0; b1 = n1;
+        }
+    }
+}
+
+__device__ __forceinline__ void gen_dot4(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
+                                         const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
+                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+    if ((KBX % CF_GEN_DEPTH) == 0 && (H16 % CF_GEN_DEPTH) == 0 && KBX + H16 >= CF_GEN_DEPTH)
+        gen_dot4_fast(acc0, acc1, acc2, acc3, w0, w1, w2, w3, xb, KBX, hb0, hb1, H16);
+    else
+        gen_dot4_any(acc0, acc1, acc2, acc3, w0, w1, w2, w3, xb, KBX, hb0, hb1, H16);
 }
 
 // ---- block 0's two k = 1 convs on the raw sample (Cin = 1): shortcut and first conv, resnet_class.py:60-66 ---------------
