@@ -19,6 +19,9 @@
 #ifndef CF_GEN_DEPTH
 #define CF_GEN_DEPTH 4
 #endif
+#ifndef CF_GEN_ABL
+#define CF_GEN_ABL 0          // timing-only ablations (tools/): 1 = no weight refills, 2 = no B-operand loads
+#endif
 __device__ __forceinline__ void gen_dot(f32x4& acc0, f32x4& acc1, const f32x4* __restrict__ wa, const f32x4* __restrict__ wb,
                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
     constexpr int D = CF_GEN_DEPTH;
@@ -106,7 +109,7 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
             for (int j = 0; j < D; ++j) {
                 const int k = k0 + j;
                 const int kn = k + 1 < KBX ? k + 1 : KBX - 1, kr = k + D < last ? k + D : last;
-                const f32x4 bn = xb[kn * 64];
+                const f32x4 bn = (CF_GEN_ABL & 2) ? b : xb[kn * 64];
                 const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -115,8 +118,9 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
                     acc2 = MFMA16(a2[i], b[i], acc2);
                     acc3 = MFMA16(a3[i], b[i], acc3);
                 }
-                A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64];
+                if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
                 b = bn;
+                __builtin_amdgcn_sched_barrier(0);          // keep the refill here, D slots ahead of its use
             }
         }
     }
@@ -127,7 +131,7 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
         for (int j = 0; j < D; ++j) {
             const int kh = k0 + j, k = KBX + kh;
             const int kn = kh + 1 < H16 ? kh + 1 : H16 - 1, kr = k + D < last ? k + D : last;
-            const f32x4 n0 = hb0[kn * 64], n1 = hb1[kn * 64];
+            const f32x4 n0 = (CF_GEN_ABL & 2) ? b0 : hb0[kn * 64], n1 = (CF_GEN_ABL & 2) ? b1 : hb1[kn * 64];
             const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -136,8 +140,9 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
                 acc2 = MFMA16(a2[i], b0[i], acc2);
                 acc3 = MFMA16(a3[i], b1[i], acc3);
             }
-            A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64];
+            if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
             b0 = n0; b1 = n1;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -235,13 +240,14 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                                                       int n_tiles) {
     constexpr bool LOCKSTEP = CF_GEN_LOCKSTEP && !TRAIN;
     extern __shared__ f32x4 gen_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dir = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int waves = blockDim.x >> 6;
+    const int dir = blockIdx.y, grp = blockIdx.x;
     // A workgroup's waves read the SAME weight stream; a barrier per output-tile group keeps them within one group of each
     // other, so that the stream (24 KB per group at H = 64) is fetched from L2 once per CU and served to the other waves by
     // the vector L1 (measured: see DESIGN.md, "Any-size path").  Waves past the last tile run on scratch tiles behind it (
     // the host rounds the buffers up to whole workgroups of tiles).
-    const int64_t tile = (int64_t)blockIdx.x * waves + wave;
+    const int64_t tile = (int64_t)grp * waves + wave;
     if (TRAIN && tile >= n_tiles) return;
     const int KB = KBX + H16;
     // state: h and r.h always in LDS; h' in a third LDS array when eight waves' worth fits (H <= 64), otherwise it takes the
@@ -329,6 +335,147 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
     }
 }
 
+
+// ---- the same layer, TWO 16-window tiles per wave ------------------------------------------------------------------------------
+// Every weight fragment a wave fetches feeds eight MFMAs instead of four: the one-tile kernel is bounded by the vector L1 that
+// serves the weight stream (0.32 accesses per CU and cycle at 52 % matrix-pipe utilisation, profiles/r02_any_size_pmc.json), not
+// by the matrix pipe.  Inference only, segment lengths multiples of the ring depth (64 or more units and input features), h'
+// through the output buffer (two LDS arrays per tile); launched when there are enough tiles to fill the chip.
+__device__ __forceinline__ void gen_dot4x2(f32x4 (&acc)[2][4], const f32x4* __restrict__ w0, const f32x4* __restrict__ w1,
+                                           const f32x4* __restrict__ w2, const f32x4* __restrict__ w3, const f32x4* __restrict__ xa,
+                                           const f32x4* __restrict__ xb, int KBX, const f32x4* a0p, const f32x4* a1p, const f32x4* b0p,
+                                           const f32x4* b1p, int H16) {
+    constexpr int D = CF_GEN_DEPTH;
+    const int KB = KBX + H16, last = KB - 1;
+    f32x4 A0[D], A1[D], A2[D], A3[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { A0[j] = w0[j * 64]; A1[j] = w1[j * 64]; A2[j] = w2[j * 64]; A3[j] = w3[j * 64]; }
+    {
+        f32x4 ba = xa[0], bb = xb[0];
+        for (int k0 = 0; k0 < KBX; k0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const int k = k0 + j;
+                const int kn = k + 1 < KBX ? k + 1 : KBX - 1, kr = k + D < last ? k + D : last;
+                const f32x4 na = (CF_GEN_ABL & 2) ? ba : xa[kn * 64], nb = (CF_GEN_ABL & 2) ? bb : xb[kn * 64];
+                const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0][0] = MFMA16(a0[i], ba[i], acc[0][0]);
+                    acc[1][0] = MFMA16(a0[i], bb[i], acc[1][0]);
+                    acc[0][1] = MFMA16(a1[i], ba[i], acc[0][1]);
+                    acc[1][1] = MFMA16(a1[i], bb[i], acc[1][1]);
+                    acc[0][2] = MFMA16(a2[i], ba[i], acc[0][2]);
+                    acc[1][2] = MFMA16(a2[i], bb[i], acc[1][2]);
+                    acc[0][3] = MFMA16(a3[i], ba[i], acc[0][3]);
+                    acc[1][3] = MFMA16(a3[i], bb[i], acc[1][3]);
+                }
+                if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
+                ba = na; bb = nb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    f32x4 pa0 = a0p[0], pa1 = a1p[0], pb0 = b0p[0], pb1 = b1p[0];       // tile a: operands of slots 0, 2 / 1, 3; tile b likewise
+    for (int k0 = 0; k0 < H16; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int kh = k0 + j, k = KBX + kh;
+            const int kn = kh + 1 < H16 ? kh + 1 : H16 - 1, kr = k + D < last ? k + D : last;
+            const f32x4 na0 = (CF_GEN_ABL & 2) ? pa0 : a0p[kn * 64], na1 = (CF_GEN_ABL & 2) ? pa1 : a1p[kn * 64];
+            const f32x4 nb0 = (CF_GEN_ABL & 2) ? pb0 : b0p[kn * 64], nb1 = (CF_GEN_ABL & 2) ? pb1 : b1p[kn * 64];
+            const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0][0] = MFMA16(a0[i], pa0[i], acc[0][0]);
+                acc[1][0] = MFMA16(a0[i], pb0[i], acc[1][0]);
+                acc[0][1] = MFMA16(a1[i], pa1[i], acc[0][1]);
+                acc[1][1] = MFMA16(a1[i], pb1[i], acc[1][1]);
+                acc[0][2] = MFMA16(a2[i], pa0[i], acc[0][2]);
+                acc[1][2] = MFMA16(a2[i], pb0[i], acc[1][2]);
+                acc[0][3] = MFMA16(a3[i], pa1[i], acc[0][3]);
+                acc[1][3] = MFMA16(a3[i], pb1[i], acc[1][3]);
+            }
+            if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
+            pa0 = na0; pa1 = na1; pb0 = nb0; pb1 = nb1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void gen_gru2_kernel(const f32x4* __restrict__ W /*[2 dirs][3: r, u, c][H16][KB][64]*/,
+                                                       const f32x4* __restrict__ Bv /*[2][3][H16][64]*/, const f32x4* __restrict__ X /*[tiles][35][KBX][64]*/,
+                                                       f32x4* Y /*[tiles][35][2 H16][64]*/, int H16, int KBX) {
+    extern __shared__ f32x4 gen_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int waves = blockDim.x >> 6;
+    const int dir = blockIdx.y, grp = blockIdx.x;
+    const int64_t tile0 = ((int64_t)grp * waves + wave) * 2;                  // tiles tile0, tile0 + 1 (scratch tiles past the end)
+    const int KB = KBX + H16;
+    f32x4* hs[2];
+    f32x4* rh[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        hs[n] = gen_lds + ((size_t)wave * 2 + n) * 2 * H16 * 64 + lane;
+        rh[n] = hs[n] + (size_t)H16 * 64;
+    }
+    const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64 + lane;
+    const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64 + lane;
+    const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64 + lane;
+    const f32x4* Br = Bv + ((size_t)(dir * 3 + 0) * H16) * 64 + lane;
+    const f32x4* Bu = Bv + ((size_t)(dir * 3 + 1) * H16) * 64 + lane;
+    const f32x4* Bc = Bv + ((size_t)(dir * 3 + 2) * H16) * 64 + lane;
+    for (int mo = 0; mo < H16; ++mo) { hs[0][mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f}; hs[1][mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int s = 0; s < CF_T; ++s) {
+        const int t = dir ? CF_T - 1 - s : s;
+        const f32x4* xt0 = X + ((tile0 * CF_T + t) * KBX) * 64 + lane;
+        const f32x4* xt1 = X + (((tile0 + 1) * CF_T + t) * KBX) * 64 + lane;
+        f32x4 acc[2][4];
+        for (int mo = 0; mo < H16; mo += 4) {                                 // reset gate, r.h
+            if (CF_GEN_LOCKSTEP) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[0][q] = Br[(mo + q) * 64]; acc[1][q] = acc[0][q]; }
+            gen_dot4x2(acc, Wr + (size_t)mo * KB * 64, Wr + (size_t)(mo + 1) * KB * 64, Wr + (size_t)(mo + 2) * KB * 64,
+                       Wr + (size_t)(mo + 3) * KB * 64, xt0, xt1, KBX, hs[0], hs[0], hs[1], hs[1], H16);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 h0 = hs[n][(mo + q) * 64];
+                    f32x4 r0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][q][j])) * h0[j];
+                    rh[n][(mo + q) * 64] = r0;
+                }
+        }
+        for (int mo = 0; mo < H16; mo += 2) {                                 // candidate and update gate, h'
+            if (CF_GEN_LOCKSTEP) __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { acc[n][0] = Bc[mo * 64]; acc[n][1] = Bu[mo * 64]; acc[n][2] = Bc[(mo + 1) * 64]; acc[n][3] = Bu[(mo + 1) * 64]; }
+            gen_dot4x2(acc, Wc + (size_t)mo * KB * 64, Wu + (size_t)mo * KB * 64, Wc + (size_t)(mo + 1) * KB * 64,
+                       Wu + (size_t)(mo + 1) * KB * 64, xt0, xt1, KBX, rh[0], hs[0], rh[1], hs[1], H16);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x4 h0 = hs[n][(mo + p) * 64];
+                    f32x4 hn;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float c = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][2 * p][j])), 1.0f);
+                        const float u = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][2 * p + 1][j]));
+                        hn[j] = fmaf(u, h0[j] - c, c);
+                    }
+                    Y[(((tile0 + n) * CF_T + t) * 2 * H16 + dir * H16 + mo + p) * 64 + lane] = hn;
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0);                                        // h' back from the output buffer (the wave's own stores)
+        for (int mo = 0; mo < H16; ++mo) {
+            hs[0][mo * 64] = Y[((tile0 * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane];
+            hs[1][mo * 64] = Y[(((tile0 + 1) * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane];
+        }
+    }
+}
 
 // Matrix-vector helper of the backward pass: out[mo] = sum_k W[mo][k] . B[k] for M16 output tiles (four at a time, two when
 // M16 < 4), B a K16-block array of this wave in LDS; epi(mo, acc) once per output tile.
@@ -452,6 +599,8 @@ struct cf_generic {
     float* g[2] = {nullptr, nullptr};                        // biGRU outputs, 2H features
     int gru_waves = 8;
     bool h_via_y = false;
+    int gru2_waves = 0;                         // gen_gru2_kernel (two tiles per wave): waves per workgroup, 0 = not used
+    size_t gru2_lds = 0;
     size_t gru_lds = 0;
 };
 

@@ -145,8 +145,8 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     cap = (cap + CF_TILE - 1) / CF_TILE * CF_TILE;
     m->cap_windows = cap;
     m->cap_tiles = cap / CF_TILE;
-    // (+ 8 tiles: the biGRU launch is whole workgroups of up to eight tiles; the waves past the last tile own scratch tiles)
-    const size_t per_f16 = (size_t)(m->cap_tiles + 8) * CF_T * 64 * sizeof(f32x4);     // bytes of one 16-feature tile plane
+    // (+ 16 tiles: the biGRU launch is whole workgroups of up to sixteen tiles; the waves past the last tile own scratch tiles)
+    const size_t per_f16 = (size_t)(m->cap_tiles + 16) * CF_T * 64 * sizeof(f32x4);    // bytes of one 16-feature tile plane
     const size_t r_bytes = per_f16 * std::max(1, g->C16), g_bytes = per_f16 * 2 * g->H16;
     const int n_r = g->C16 > 0 ? 4 : 1;
     for (int i = 0; i < n_r; ++i) {
@@ -167,7 +167,14 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     g->h_via_y = per_wave * 8 > (size_t)(160 * 1024);
     if (g->h_via_y) per_wave = (size_t)2 * g->H16 * 64 * sizeof(f32x4);
     g->gru_waves = per_wave * 8 <= (size_t)(160 * 1024) ? 8 : 4;
+    if (getenv("CATFISH_GEN_WAVES")) g->gru_waves = std::max(1, std::min(g->gru_waves, atoi(getenv("CATFISH_GEN_WAVES"))));    // A/B knob for tools/
     g->gru_lds = per_wave * g->gru_waves;
+    // two tiles per wave (gen_gru2_kernel): two LDS arrays per tile; 8 or 4 waves per workgroup, else not used
+    const size_t per_wave2 = (size_t)2 * 2 * g->H16 * 64 * sizeof(f32x4);
+    g->gru2_waves = (g->H16 % 4) != 0 || getenv("CATFISH_GEN_ONE_TILE") ? 0 : (per_wave2 * 8 <= (size_t)(160 * 1024) ? 8 : (per_wave2 * 4 <= (size_t)(160 * 1024) ? 4 : 0));
+    g->gru2_lds = per_wave2 * g->gru2_waves;
+    if (g->gru2_waves)
+        HIP_TRY(hipFuncSetAttribute((const void*)gen_gru2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru2_lds));
     HIP_TRY(hipFuncSetAttribute((const void*)gen_gru_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru_lds));
     HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gru_pack_floats(16) * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)gru_layer_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gru_pack_floats(32) * 4));
@@ -235,9 +242,19 @@ static int gen_run_pass(cf_model* m, const float* x, int64_t n_windows, float* p
             continue;
         }
         if ((rc = prof_begin(m, slot, s, &pi)) != CF_OK) return rc;
+        if (g->gru2_waves && (L.kbx % 4) == 0 && n_tiles >= 2 * m->n_cu) {          // enough tiles to fill the chip two per wave
+            const int pairs = (n_tiles + 1) / 2, gx = (pairs + g->gru2_waves - 1) / g->gru2_waves;
+            hipLaunchKernelGGL(gen_gru2_kernel, dim3((unsigned)gx, 2), dim3(g->gru2_waves * 64), g->gru2_lds, s,
+                               L.w, L.b, cur, G[l & 1], g->H16, L.kbx);
+            HIP_TRY(hipGetLastError());
+            if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+            cur = G[l & 1];
+            continue;
+        }
         // small calls (the reference's one-read-per-call pattern): fewer waves per workgroup, so that the tiles spread over the CUs
         const int waves = std::max(1, std::min(g->gru_waves, (2 * n_tiles + m->n_cu - 1) / m->n_cu));
-        hipLaunchKernelGGL(gen_gru_kernel<false>, dim3((unsigned)((n_tiles + waves - 1) / waves), 2), dim3(waves * 64), g->gru_lds / g->gru_waves * waves, s,
+        const int gx = (n_tiles + waves - 1) / waves;
+        hipLaunchKernelGGL(gen_gru_kernel<false>, dim3((unsigned)gx, 2), dim3(waves * 64), g->gru_lds / g->gru_waves * waves, s,
                            L.w, L.b, cur, G[l & 1], g->H16, L.kbx, g->h_via_y ? 1 : 0, (f32x4*)nullptr, n_tiles);
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;

@@ -279,6 +279,32 @@ def test_unsupported_geometries_are_refused():
         HipEngine(w, layer_size=128, layer_size_res=32, n_layers=1, n_layers_res=1, device=0, max_windows_per_pass=64, precision="bf16")
 
 
+@pytest.mark.parametrize("h,c,n_layers,n_layers_res,n", [(128, 64, 2, 1, 9001), (64, 64, 2, 1, 8400), (128, 0, 2, 0, 8200)])
+def test_any_size_two_tile_kernel_is_bit_identical_to_the_one_tile_kernel(h, c, n_layers, n_layers_res, n, monkeypatch):
+    """Big launches of 64- and 128-unit models run two 16-window tiles per wave (gen_gru2_kernel: every weight fragment feeds
+    eight MFMAs); the result must equal the one-tile kernel's bit for bit (CATFISH_GEN_ONE_TILE=1 and, independently, small
+    calls, which never use it), and a sample is checked against the fp64 oracle."""
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=60 + h, layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res)
+    x = np.random.default_rng(h).normal(0, 1.3, size=(n, 35)).astype(np.float32)
+    kw = dict(layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res, device=0, max_windows_per_pass=16384)
+    two = HipEngine(w, **kw)
+    monkeypatch.setenv("CATFISH_GEN_ONE_TILE", "1")
+    one = HipEngine(w, **kw)
+    monkeypatch.delenv("CATFISH_GEN_ONE_TILE")
+    try:
+        a, b = two.infer_host(x), one.infer_host(x)
+        assert np.array_equal(a, b)
+        assert np.array_equal(two.infer_host(x[5000:5300]), a[5000 * 35:5300 * 35])       # a small call: the one-tile kernel
+        idx = np.concatenate([np.arange(0, 40), np.arange(n - 40, n), [4095, 4096, 8191]])
+        idx = idx[idx < n]
+        want = oracle.forward(x[idx], w, np.float64, n_layers=n_layers, n_layers_res=n_layers_res).reshape(len(idx), 35)
+        assert np.abs(a.reshape(n, 35)[idx] - want).max() < TOL
+        two.check_error()
+    finally:
+        two.close(); one.close()
+
+
 def test_any_size_path_agrees_with_the_tuned_kernels_on_the_checkpoint(ckpt_weights, monkeypatch):
     """CATFISH_GENERIC=1 sends the shipped geometry through the any-size kernels too: same checkpoint, same reads, the two
     implementations agree to 2e-6 and both sit within 1e-4 of the fp64 oracle; bf16 is refused on that path."""
