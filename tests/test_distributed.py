@@ -232,3 +232,52 @@ def test_a_failing_rank_fails_the_whole_sharded_run_without_hanging(tmp_path):
     r0, r1 = (tmp_path / "rank0").read_text(), (tmp_path / "rank1").read_text()
     assert r1.startswith("ValueError") and "FAST5" in r1
     assert r0.startswith("RuntimeError") and "rank 1" in r0 and "FAST5" in r0
+
+
+def _eight_rank_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from catfish_amd import sharding
+    from oracle import catfish_oracle as oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    assert sharding.init_host_group()
+    try:
+        w = oracle.random_weights(seed=3, layer_size=16, n_layers=1, layer_size_res=16, n_layers_res=1)
+        w["final_fully_connected/bias"] = np.array([0.4], np.float32)          # random weights: some samples over 0.5
+
+        def infer_read(r):
+            x = oracle.pad_and_window(oracle.normalize_raw_signal(np.asarray(r)))[0]
+            p = oracle.forward(x, w, np.float32, n_layers=1, n_layers_res=1)[:len(r)]
+            return oracle.hp_in_pred(oracle.correct_short(oracle.class_from_threshold(p))), len(r)
+
+        class Runner(sharding.EngineBatchRunner):
+            def __init__(self):
+                pass
+
+            def run(self, batches, compact=False):
+                for reads in batches:
+                    res = [infer_read(r) for r in reads]
+                    yield sharding.SpanTable.from_lists(res) if compact else res
+
+        for n_reads in (19, 5):                        # more reads than ranks; fewer reads than ranks (empty shards)
+            dacs = [oracle.synthetic_dac(1, 300 + 97 * i, seed=70 + i)[0] for i in range(n_reads)]
+            res = sharding.infer_reads_sharded(None, dacs, max_samples_per_batch=900, batch_runner=Runner(),
+                                               gather_group=sharding.host_gather_group())
+            if rank == 0:
+                assert res == [infer_read(d) for d in dacs]
+                open(os.path.join(tmpdir, "ok8_%d" % n_reads), "w").write("ok")
+            else:
+                assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_gather_of_span_tables_with_empty_shards(tmp_path):
+    """The N = 8 shape of BASELINE configs[2] on CPU (gloo): eight ranks, LPT shards, each rank hands a SpanTable to the host
+    gather, rank 0 rebuilds the per-read lists in input order -- with more reads than ranks and with fewer (three ranks hold
+    nothing and still take part in the collective)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_eight_rank_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert (tmp_path / "ok8_19").exists() and (tmp_path / "ok8_5").exists()
