@@ -19,18 +19,30 @@
 #ifndef CF_GEN_DEPTH
 #define CF_GEN_DEPTH 4
 #endif
+#ifndef CF_GEN_STAMP
+#define CF_GEN_STAMP 0        // diagnostic build: per-phase s_memtime cycles of one wave of gen_gru2_kernel, printed at the end
+#endif
 #ifndef CF_GEN_ABL
 #define CF_GEN_ABL 0          // timing-only ablations (tools/): 1 = no weight refills, 2 = no B-operand loads
 #endif
+// Load through a UNIFORM pointer plus the lane's byte offset.  The empty asm makes the lane term opaque per use: otherwise the
+// compiler folds it into a loop-invariant per-lane base pointer and adds the (scalar) k offset to it with 64-bit VALU
+// arithmetic for every load; this way the address stays an SGPR base + one VGPR offset (global_load ... v, s[base]).
+__device__ __forceinline__ f32x4 gen_ld(const f32x4* __restrict__ p, unsigned ln) {
+    unsigned off = ln * 16u;
+    asm volatile("" : "+v"(off));
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p) + off);
+}
+
 __device__ __forceinline__ void gen_dot(f32x4& acc0, f32x4& acc1, const f32x4* __restrict__ wa, const f32x4* __restrict__ wb,
-                                        const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+                                        const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16, unsigned ln) {
     constexpr int D = CF_GEN_DEPTH;
     const int KB = KBX + H16;
     f32x4 A0[D], A1[D], B0[D], B1[D];
     auto fetch = [&](int j, int k) {
-        A0[j] = wa[k * 64];
-        A1[j] = wb[k * 64];
-        if (k < KBX) { B0[j] = xb[k * 64]; B1[j] = B0[j]; }
+        A0[j] = gen_ld(wa + k * 64, ln);
+        A1[j] = gen_ld(wb + k * 64, ln);
+        if (k < KBX) { B0[j] = gen_ld(xb + k * 64, ln); B1[j] = B0[j]; }
         else { B0[j] = hb0[(k - KBX) * 64]; B1[j] = hb1[(k - KBX) * 64]; }
     };
 #pragma unroll
@@ -56,16 +68,16 @@ __device__ __forceinline__ void gen_dot(f32x4& acc0, f32x4& acc1, const f32x4* _
 // The same with four output tiles (four independent MFMA chains): acc0, acc2 use B0 and acc1, acc3 use B1.
 __device__ __forceinline__ void gen_dot4_any(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
                                              const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
-                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16, unsigned ln) {
     constexpr int D = CF_GEN_DEPTH;
     const int KB = KBX + H16;
     f32x4 A0[D], A1[D], A2[D], A3[D], B0[D], B1[D];
     auto fetch = [&](int j, int k) {
-        A0[j] = w0[k * 64];
-        A1[j] = w1[k * 64];
-        A2[j] = w2[k * 64];
-        A3[j] = w3[k * 64];
-        if (k < KBX) { B0[j] = xb[k * 64]; B1[j] = B0[j]; }
+        A0[j] = gen_ld(w0 + k * 64, ln);
+        A1[j] = gen_ld(w1 + k * 64, ln);
+        A2[j] = gen_ld(w2 + k * 64, ln);
+        A3[j] = gen_ld(w3 + k * 64, ln);
+        if (k < KBX) { B0[j] = gen_ld(xb + k * 64, ln); B1[j] = B0[j]; }
         else { B0[j] = hb0[(k - KBX) * 64]; B1[j] = hb1[(k - KBX) * 64]; }
     };
 #pragma unroll
@@ -96,20 +108,20 @@ __device__ __forceinline__ void gen_dot4_any(f32x4& acc0, f32x4& acc1, f32x4& ac
 // vmcnt(0..5) in the ISA, and the matrix pipe was busy 51 % of the time).
 __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
                                               const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
-                                              const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+                                              const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16, unsigned ln) {
     constexpr int D = CF_GEN_DEPTH;
     const int KB = KBX + H16, last = KB - 1;
     f32x4 A0[D], A1[D], A2[D], A3[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) { A0[j] = w0[j * 64]; A1[j] = w1[j * 64]; A2[j] = w2[j * 64]; A3[j] = w3[j * 64]; }
+    for (int j = 0; j < D; ++j) { A0[j] = gen_ld(w0 + j * 64, ln); A1[j] = gen_ld(w1 + j * 64, ln); A2[j] = gen_ld(w2 + j * 64, ln); A3[j] = gen_ld(w3 + j * 64, ln); }
     if (KBX > 0) {
-        f32x4 b = xb[0];
+        f32x4 b = gen_ld(xb, ln);
         for (int k0 = 0; k0 < KBX; k0 += D) {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const int k = k0 + j;
                 const int kn = k + 1 < KBX ? k + 1 : KBX - 1, kr = k + D < last ? k + D : last;
-                const f32x4 bn = (CF_GEN_ABL & 2) ? b : xb[kn * 64];
+                const f32x4 bn = (CF_GEN_ABL & 2) ? b : gen_ld(xb + kn * 64, ln);
                 const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -118,7 +130,7 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
                     acc2 = MFMA16(a2[i], b[i], acc2);
                     acc3 = MFMA16(a3[i], b[i], acc3);
                 }
-                if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
+                if (!(CF_GEN_ABL & 1)) { A0[j] = gen_ld(w0 + kr * 64, ln); A1[j] = gen_ld(w1 + kr * 64, ln); A2[j] = gen_ld(w2 + kr * 64, ln); A3[j] = gen_ld(w3 + kr * 64, ln); }
                 b = bn;
                 __builtin_amdgcn_sched_barrier(0);          // keep the refill here, D slots ahead of its use
             }
@@ -140,7 +152,7 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
                 acc2 = MFMA16(a2[i], b0[i], acc2);
                 acc3 = MFMA16(a3[i], b1[i], acc3);
             }
-            if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
+            if (!(CF_GEN_ABL & 1)) { A0[j] = gen_ld(w0 + kr * 64, ln); A1[j] = gen_ld(w1 + kr * 64, ln); A2[j] = gen_ld(w2 + kr * 64, ln); A3[j] = gen_ld(w3 + kr * 64, ln); }
             b0 = n0; b1 = n1;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -149,11 +161,11 @@ __device__ __forceinline__ void gen_dot4_fast(f32x4& acc0, f32x4& acc1, f32x4& a
 
 __device__ __forceinline__ void gen_dot4(f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3, const f32x4* __restrict__ w0,
                                          const f32x4* __restrict__ w1, const f32x4* __restrict__ w2, const f32x4* __restrict__ w3,
-                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16) {
+                                         const f32x4* __restrict__ xb, int KBX, const f32x4* hb0, const f32x4* hb1, int H16, unsigned ln) {
     if ((KBX % CF_GEN_DEPTH) == 0 && (H16 % CF_GEN_DEPTH) == 0 && KBX + H16 >= CF_GEN_DEPTH)
-        gen_dot4_fast(acc0, acc1, acc2, acc3, w0, w1, w2, w3, xb, KBX, hb0, hb1, H16);
+        gen_dot4_fast(acc0, acc1, acc2, acc3, w0, w1, w2, w3, xb, KBX, hb0, hb1, H16, ln);
     else
-        gen_dot4_any(acc0, acc1, acc2, acc3, w0, w1, w2, w3, xb, KBX, hb0, hb1, H16);
+        gen_dot4_any(acc0, acc1, acc2, acc3, w0, w1, w2, w3, xb, KBX, hb0, hb1, H16, ln);
 }
 
 // ---- block 0's two k = 1 convs on the raw sample (Cin = 1): shortcut and first conv, resnet_class.py:60-66 ---------------
@@ -186,7 +198,8 @@ __global__ __launch_bounds__(256) void gen_first_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__ W /*[taps][Co16][Ki16][64]*/, const f32x4* __restrict__ Bv /*[Co16][64]*/,
                                                        const f32x4* __restrict__ X, const f32x4* __restrict__ R /*residual or null*/,
                                                        f32x4* __restrict__ Y, int n_tiles, int Ki16, int Co16, int taps, int relu /*1: before the residual add, 2: after*/) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave: uniform
+    const unsigned ln = lane;
     const int64_t n_tasks = (int64_t)n_tiles * CF_T;
     for (int64_t task = (int64_t)blockIdx.x * 4 + wave; task < n_tasks; task += (int64_t)gridDim.x * 4) {
         const int64_t tile = task / CF_T;
@@ -197,10 +210,10 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__
             for (int tap = 0; tap < taps; ++tap) {
                 const int tt = t + tap - (taps >> 1);
                 if (tt < 0 || tt >= CF_T) continue;                           // zero padding at the window edges
-                const f32x4* xb = X + ((tile * CF_T + tt) * Ki16) * 64 + lane;
-                const f32x4* wa = W + ((int64_t)(tap * Co16 + mo) * Ki16) * 64 + lane;
-                const f32x4* wb = W + ((int64_t)(tap * Co16 + m1) * Ki16) * 64 + lane;
-                gen_dot(acc0, acc1, wa, wb, xb, Ki16, nullptr, nullptr, 0);
+                const f32x4* xb = X + ((tile * CF_T + tt) * Ki16) * 64;       // uniform pointers, lane added at the access
+                const f32x4* wa = W + ((int64_t)(tap * Co16 + mo) * Ki16) * 64;
+                const f32x4* wb = W + ((int64_t)(tap * Co16 + m1) * Ki16) * 64;
+                gen_dot(acc0, acc1, wa, wb, xb, Ki16, nullptr, nullptr, 0, ln);
             }
             f32x4* y0 = Y + ((tile * CF_T + t) * Co16 + mo) * 64 + lane;
             f32x4* y1 = Y + ((tile * CF_T + t) * Co16 + m1) * 64 + lane;
@@ -240,7 +253,8 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                                                       int n_tiles) {
     constexpr bool LOCKSTEP = CF_GEN_LOCKSTEP && !TRAIN;
     extern __shared__ f32x4 gen_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave: uniform (SGPR)
+    const unsigned ln = lane;
     const int waves = blockDim.x >> 6;
     const int dir = blockIdx.y, grp = blockIdx.x;
     // A workgroup's waves read the SAME weight stream; a barrier per output-tile group keeps them within one group of each
@@ -256,16 +270,16 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
     f32x4* hs = gen_lds + (size_t)wave * arrays * H16 * 64 + lane;
     f32x4* rh = hs + (size_t)H16 * 64;
     f32x4* cs = rh + (size_t)H16 * 64;                            // only with three arrays
-    const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64 + lane;
-    const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64 + lane;
-    const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64 + lane;
+    const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64;          // uniform pointers: the lane is added at the access
+    const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64;
+    const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64;
     const f32x4* Br = Bv + ((size_t)(dir * 3 + 0) * H16) * 64 + lane;
     const f32x4* Bu = Bv + ((size_t)(dir * 3 + 1) * H16) * 64 + lane;
     const f32x4* Bc = Bv + ((size_t)(dir * 3 + 2) * H16) * 64 + lane;
     for (int mo = 0; mo < H16; ++mo) hs[mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f};       // GRUCellZeroState
     for (int s = 0; s < CF_T; ++s) {
         const int t = dir ? CF_T - 1 - s : s;                     // ReverseV2 around the backward direction
-        const f32x4* xt = X + ((tile * CF_T + t) * KBX) * 64 + lane;
+        const f32x4* xt = X + ((tile * CF_T + t) * KBX) * 64;
         // reset gate, then r.h (gru_cell/mul -> concat_1): four output tiles at a time (two when H < 64)
         auto reset_tile = [&](int mo, const f32x4& acc) {
             const f32x4 h0 = hs[mo * 64];
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                 if (LOCKSTEP) __syncthreads();
                 f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64], acc2 = Br[m2 * 64], acc3 = Br[m3 * 64];
                 gen_dot4(acc0, acc1, acc2, acc3, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, Wr + (size_t)m2 * KB * 64,
-                         Wr + (size_t)m3 * KB * 64, xt, KBX, hs, hs, H16);
+                         Wr + (size_t)m3 * KB * 64, xt, KBX, hs, hs, H16, ln);
                 reset_tile(mo, acc0); reset_tile(m1, acc1); reset_tile(m2, acc2); reset_tile(m3, acc3);
             }
         } else {
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                 const int m1 = mo + 1 < H16 ? mo + 1 : mo;
                 if (LOCKSTEP) __syncthreads();
                 f32x4 acc0 = Br[mo * 64], acc1 = Br[m1 * 64];
-                gen_dot(acc0, acc1, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, xt, KBX, hs, hs, H16);
+                gen_dot(acc0, acc1, Wr + (size_t)mo * KB * 64, Wr + (size_t)m1 * KB * 64, xt, KBX, hs, hs, H16, ln);
                 reset_tile(mo, acc0); reset_tile(m1, acc1);
             }
         }
@@ -316,14 +330,14 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
                 if (LOCKSTEP) __syncthreads();
                 f32x4 c0 = Bc[mo * 64], u0 = Bu[mo * 64], c1 = Bc[m1 * 64], u1 = Bu[m1 * 64];
                 gen_dot4(c0, u0, c1, u1, Wc + (size_t)mo * KB * 64, Wu + (size_t)mo * KB * 64, Wc + (size_t)m1 * KB * 64,
-                         Wu + (size_t)m1 * KB * 64, xt, KBX, rh, hs, H16);
+                         Wu + (size_t)m1 * KB * 64, xt, KBX, rh, hs, H16, ln);
                 update_tile(mo, c0, u0);
                 if (m1 != mo) update_tile(m1, c1, u1);
             }
         } else {
             if (LOCKSTEP) __syncthreads();
             f32x4 c0 = Bc[0], u0 = Bu[0];
-            gen_dot(c0, u0, Wc, Wu, xt, KBX, rh, hs, H16);
+            gen_dot(c0, u0, Wc, Wu, xt, KBX, rh, hs, H16, ln);
             update_tile(0, c0, u0);
         }
         if (h_via_y) {
@@ -341,23 +355,43 @@ __global__ __launch_bounds__(512) void gen_gru_kernel(const f32x4* __restrict__ 
 // serves the weight stream (0.32 accesses per CU and cycle at 52 % matrix-pipe utilisation, profiles/r02_any_size_pmc.json), not
 // by the matrix pipe.  Inference only, segment lengths multiples of the ring depth (64 or more units and input features), h'
 // through the output buffer (two LDS arrays per tile); launched when there are enough tiles to fill the chip.
-__device__ __forceinline__ void gen_dot4x2(f32x4 (&acc)[2][4], const f32x4* __restrict__ w0, const f32x4* __restrict__ w1,
-                                           const f32x4* __restrict__ w2, const f32x4* __restrict__ w3, const f32x4* __restrict__ xa,
-                                           const f32x4* __restrict__ xb, int KBX, const f32x4* a0p, const f32x4* a1p, const f32x4* b0p,
-                                           const f32x4* b1p, int H16) {
-    constexpr int D = CF_GEN_DEPTH;
-    const int KB = KBX + H16, last = KB - 1;
-    f32x4 A0[D], A1[D], A2[D], A3[D];
+// The weight ring (A0..A3: the next D k-blocks of the four streams) lives across calls: a call consumes it and its refills run
+// on into the streams of the NEXT call (n0..n3), so no call starts with an empty ring (a refill at the start of every call cost
+// 7-13 k cycles of a 25 k-cycle call, profiles/r02_any_size_stamps.log).  gen_ring_fill primes it once per pass sequence.
+struct gen_ring { f32x4 A0[CF_GEN_DEPTH], A1[CF_GEN_DEPTH], A2[CF_GEN_DEPTH], A3[CF_GEN_DEPTH]; };
+
+// Global pointers here are UNIFORM (no lane term): the lane offset is added at the access, so that the address is an SGPR base
+// plus one constant VGPR offset -- no 64-bit VALU address arithmetic per load (fp32 MFMA and VALU do not overlap: every
+// v_lshl_add_u64 in the loop was lost matrix time).
+__device__ __forceinline__ void gen_ring_fill(gen_ring& r, const f32x4* __restrict__ w0, const f32x4* __restrict__ w1,
+                                              const f32x4* __restrict__ w2, const f32x4* __restrict__ w3, unsigned ln) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) { A0[j] = w0[j * 64]; A1[j] = w1[j * 64]; A2[j] = w2[j * 64]; A3[j] = w3[j * 64]; }
+    for (int j = 0; j < CF_GEN_DEPTH; ++j) { r.A0[j] = (w0 + j * 64)[ln]; r.A1[j] = (w1 + j * 64)[ln]; r.A2[j] = (w2 + j * 64)[ln]; r.A3[j] = (w3 + j * 64)[ln]; }
+}
+
+__device__ __forceinline__ void gen_dot4x2(f32x4 (&acc)[2][4], gen_ring& ring, const f32x4* __restrict__ w0, const f32x4* __restrict__ w1,
+                                           const f32x4* __restrict__ w2, const f32x4* __restrict__ w3, const f32x4* __restrict__ n0,
+                                           const f32x4* __restrict__ n1, const f32x4* __restrict__ n2, const f32x4* __restrict__ n3,
+                                           const f32x4* __restrict__ xa, const f32x4* __restrict__ xb, int KBX, const f32x4* a0p,
+                                           const f32x4* a1p, const f32x4* b0p, const f32x4* b1p, int H16, unsigned ln) {
+    constexpr int D = CF_GEN_DEPTH;
+    const int KB = KBX + H16;
+    f32x4 (&A0)[D] = ring.A0, (&A1)[D] = ring.A1, (&A2)[D] = ring.A2, (&A3)[D] = ring.A3;
+    // refill source of k-block kr = k + D: this call's streams, or (kr >= KB) the first blocks of the next call's
+    auto refill = [&](int j, int kr) {
+        if (CF_GEN_ABL & 1) return;
+        const bool nxt = kr >= KB;
+        const int ko = (nxt ? kr - KB : kr) * 64;
+        A0[j] = ((nxt ? n0 : w0) + ko)[ln]; A1[j] = ((nxt ? n1 : w1) + ko)[ln]; A2[j] = ((nxt ? n2 : w2) + ko)[ln]; A3[j] = ((nxt ? n3 : w3) + ko)[ln];
+    };
     {
-        f32x4 ba = xa[0], bb = xb[0];
+        f32x4 ba = xa[ln], bb = xb[ln];
         for (int k0 = 0; k0 < KBX; k0 += D) {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const int k = k0 + j;
-                const int kn = k + 1 < KBX ? k + 1 : KBX - 1, kr = k + D < last ? k + D : last;
-                const f32x4 na = (CF_GEN_ABL & 2) ? ba : xa[kn * 64], nb = (CF_GEN_ABL & 2) ? bb : xb[kn * 64];
+                const int kn = k + 1 < KBX ? k + 1 : KBX - 1;
+                const f32x4 na = (CF_GEN_ABL & 2) ? ba : (xa + kn * 64)[ln], nb = (CF_GEN_ABL & 2) ? bb : (xb + kn * 64)[ln];
                 const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -370,7 +404,7 @@ __device__ __forceinline__ void gen_dot4x2(f32x4 (&acc)[2][4], const f32x4* __re
                     acc[0][3] = MFMA16(a3[i], ba[i], acc[0][3]);
                     acc[1][3] = MFMA16(a3[i], bb[i], acc[1][3]);
                 }
-                if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
+                refill(j, k + D);
                 ba = na; bb = nb;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -381,7 +415,7 @@ __device__ __forceinline__ void gen_dot4x2(f32x4 (&acc)[2][4], const f32x4* __re
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int kh = k0 + j, k = KBX + kh;
-            const int kn = kh + 1 < H16 ? kh + 1 : H16 - 1, kr = k + D < last ? k + D : last;
+            const int kn = kh + 1 < H16 ? kh + 1 : H16 - 1;
             const f32x4 na0 = (CF_GEN_ABL & 2) ? pa0 : a0p[kn * 64], na1 = (CF_GEN_ABL & 2) ? pa1 : a1p[kn * 64];
             const f32x4 nb0 = (CF_GEN_ABL & 2) ? pb0 : b0p[kn * 64], nb1 = (CF_GEN_ABL & 2) ? pb1 : b1p[kn * 64];
             const f32x4 a0 = A0[j], a1 = A1[j], a2 = A2[j], a3 = A3[j];
@@ -396,7 +430,7 @@ __device__ __forceinline__ void gen_dot4x2(f32x4 (&acc)[2][4], const f32x4* __re
                 acc[0][3] = MFMA16(a3[i], pa1[i], acc[0][3]);
                 acc[1][3] = MFMA16(a3[i], pb1[i], acc[1][3]);
             }
-            if (!(CF_GEN_ABL & 1)) { A0[j] = w0[kr * 64]; A1[j] = w1[kr * 64]; A2[j] = w2[kr * 64]; A3[j] = w3[kr * 64]; }
+            refill(j, k + D);
             pa0 = na0; pa1 = na1; pb0 = nb0; pb1 = nb1;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -407,7 +441,8 @@ __global__ __launch_bounds__(512) void gen_gru2_kernel(const f32x4* __restrict__
                                                        const f32x4* __restrict__ Bv /*[2][3][H16][64]*/, const f32x4* __restrict__ X /*[tiles][35][KBX][64]*/,
                                                        f32x4* Y /*[tiles][35][2 H16][64]*/, int H16, int KBX) {
     extern __shared__ f32x4 gen_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave: uniform (SGPR)
+    const unsigned ln = lane;
     const int waves = blockDim.x >> 6;
     const int dir = blockIdx.y, grp = blockIdx.x;
     const int64_t tile0 = ((int64_t)grp * waves + wave) * 2;                  // tiles tile0, tile0 + 1 (scratch tiles past the end)
@@ -419,24 +454,42 @@ __global__ __launch_bounds__(512) void gen_gru2_kernel(const f32x4* __restrict__
         hs[n] = gen_lds + ((size_t)wave * 2 + n) * 2 * H16 * 64 + lane;
         rh[n] = hs[n] + (size_t)H16 * 64;
     }
-    const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64 + lane;
-    const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64 + lane;
-    const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64 + lane;
-    const f32x4* Br = Bv + ((size_t)(dir * 3 + 0) * H16) * 64 + lane;
-    const f32x4* Bu = Bv + ((size_t)(dir * 3 + 1) * H16) * 64 + lane;
-    const f32x4* Bc = Bv + ((size_t)(dir * 3 + 2) * H16) * 64 + lane;
+    const f32x4* Wr = W + ((size_t)(dir * 3 + 0) * H16 * KB) * 64;          // uniform pointers: the lane is added at the access
+    const f32x4* Wu = W + ((size_t)(dir * 3 + 1) * H16 * KB) * 64;
+    const f32x4* Wc = W + ((size_t)(dir * 3 + 2) * H16 * KB) * 64;
+    const f32x4* Br = Bv + ((size_t)(dir * 3 + 0) * H16) * 64;
+    const f32x4* Bu = Bv + ((size_t)(dir * 3 + 1) * H16) * 64;
+    const f32x4* Bc = Bv + ((size_t)(dir * 3 + 2) * H16) * 64;
     for (int mo = 0; mo < H16; ++mo) { hs[0][mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f}; hs[1][mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    long long st_[6] = {0, 0, 0, 0, 0, 0};
+    gen_ring ring;
     for (int s = 0; s < CF_T; ++s) {
         const int t = dir ? CF_T - 1 - s : s;
-        const f32x4* xt0 = X + ((tile0 * CF_T + t) * KBX) * 64 + lane;
-        const f32x4* xt1 = X + (((tile0 + 1) * CF_T + t) * KBX) * 64 + lane;
+        const f32x4* xt0 = X + ((tile0 * CF_T + t) * KBX) * 64;
+        const f32x4* xt1 = X + (((tile0 + 1) * CF_T + t) * KBX) * 64;
         f32x4 acc[2][4];
+        // stream bases of call c of this step: c < nr: reset-gate group c; then candidate / update group c - nr; then the next step's first
+        const int nr = H16 / 4, ncu = H16 / 2;
+        auto stream = [&](int c, int q) -> const f32x4* {
+            if (c >= nr + ncu) c = 0;                                         // (the ring runs on into the next step: same weights)
+            if (c < nr) return Wr + (size_t)(4 * c + q) * KB * 64;
+            const int mo = 2 * (c - nr) + (q >> 1);
+            return ((q & 1) ? Wu : Wc) + (size_t)mo * KB * 64;
+        };
+        if (s == 0) gen_ring_fill(ring, stream(0, 0), stream(0, 1), stream(0, 2), stream(0, 3), ln);
+        long long ts_ = CF_GEN_STAMP ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define CF_GSTAMP(i) if (CF_GEN_STAMP) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); st_[i] += tn_ - ts_; ts_ = tn_; }
         for (int mo = 0; mo < H16; mo += 4) {                                 // reset gate, r.h
             if (CF_GEN_LOCKSTEP) __syncthreads();
+            CF_GSTAMP(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { acc[0][q] = Br[(mo + q) * 64]; acc[1][q] = acc[0][q]; }
-            gen_dot4x2(acc, Wr + (size_t)mo * KB * 64, Wr + (size_t)(mo + 1) * KB * 64, Wr + (size_t)(mo + 2) * KB * 64,
-                       Wr + (size_t)(mo + 3) * KB * 64, xt0, xt1, KBX, hs[0], hs[0], hs[1], hs[1], H16);
+            for (int q = 0; q < 4; ++q) { acc[0][q] = (Br + (mo + q) * 64)[ln]; acc[1][q] = acc[0][q]; }
+            {
+                const int c = mo / 4;
+                gen_dot4x2(acc, ring, stream(c, 0), stream(c, 1), stream(c, 2), stream(c, 3), stream(c + 1, 0), stream(c + 1, 1),
+                           stream(c + 1, 2), stream(c + 1, 3), xt0, xt1, KBX, hs[0], hs[0], hs[1], hs[1], H16, ln);
+            }
+            CF_GSTAMP(1);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -447,13 +500,19 @@ __global__ __launch_bounds__(512) void gen_gru2_kernel(const f32x4* __restrict__
                     for (int j = 0; j < 4; ++j) r0[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[n][q][j])) * h0[j];
                     rh[n][(mo + q) * 64] = r0;
                 }
+            CF_GSTAMP(2);
         }
         for (int mo = 0; mo < H16; mo += 2) {                                 // candidate and update gate, h'
             if (CF_GEN_LOCKSTEP) __syncthreads();
+            CF_GSTAMP(0);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) { acc[n][0] = Bc[mo * 64]; acc[n][1] = Bu[mo * 64]; acc[n][2] = Bc[(mo + 1) * 64]; acc[n][3] = Bu[(mo + 1) * 64]; }
-            gen_dot4x2(acc, Wc + (size_t)mo * KB * 64, Wu + (size_t)mo * KB * 64, Wc + (size_t)(mo + 1) * KB * 64,
-                       Wu + (size_t)(mo + 1) * KB * 64, xt0, xt1, KBX, rh[0], hs[0], rh[1], hs[1], H16);
+            for (int n = 0; n < 2; ++n) { acc[n][0] = (Bc + mo * 64)[ln]; acc[n][1] = (Bu + mo * 64)[ln]; acc[n][2] = (Bc + (mo + 1) * 64)[ln]; acc[n][3] = (Bu + (mo + 1) * 64)[ln]; }
+            {
+                const int c = nr + mo / 2;
+                gen_dot4x2(acc, ring, stream(c, 0), stream(c, 1), stream(c, 2), stream(c, 3), stream(c + 1, 0), stream(c + 1, 1),
+                           stream(c + 1, 2), stream(c + 1, 3), xt0, xt1, KBX, rh[0], hs[0], rh[1], hs[1], H16, ln);
+            }
+            CF_GSTAMP(3);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -468,26 +527,32 @@ __global__ __launch_bounds__(512) void gen_gru2_kernel(const f32x4* __restrict__
                     }
                     Y[(((tile0 + n) * CF_T + t) * 2 * H16 + dir * H16 + mo + p) * 64 + lane] = hn;
                 }
+            CF_GSTAMP(4);
         }
         __builtin_amdgcn_s_waitcnt(0);                                        // h' back from the output buffer (the wave's own stores)
         for (int mo = 0; mo < H16; ++mo) {
             hs[0][mo * 64] = Y[((tile0 * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane];
             hs[1][mo * 64] = Y[(((tile0 + 1) * CF_T + t) * 2 * H16 + dir * H16 + mo) * 64 + lane];
         }
+        CF_GSTAMP(5);
     }
+#undef CF_GSTAMP
+    if (CF_GEN_STAMP && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        printf("gen_gru2 stamps (cycles over 35 steps, wave 0): barrier %lld  r-dot %lld  r-epilogue %lld  cu-dot %lld  cu-epilogue %lld  readback %lld  (H16 %d KBX %d)\n",
+               st_[0], st_[1], st_[2], st_[3], st_[4], st_[5], H16, KBX);
 }
 
 // Matrix-vector helper of the backward pass: out[mo] = sum_k W[mo][k] . B[k] for M16 output tiles (four at a time, two when
 // M16 < 4), B a K16-block array of this wave in LDS; epi(mo, acc) once per output tile.
 template <typename EP>
-__device__ __forceinline__ void gen_matvec(const f32x4* __restrict__ W /*lane-offset [M16][K16][64]*/, int M16, int K16, const f32x4* B, EP epi) {
+__device__ __forceinline__ void gen_matvec(const f32x4* __restrict__ W /*uniform pointer [M16][K16][64]*/, int M16, int K16, const f32x4* B, EP epi, unsigned ln) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     if (M16 >= 4) {
         for (int mo = 0; mo < M16; mo += 4) {
             const int m1 = mo + 1 < M16 ? mo + 1 : mo, m2 = mo + 2 < M16 ? mo + 2 : mo, m3 = mo + 3 < M16 ? mo + 3 : mo;
             f32x4 a0 = z, a1 = z, a2 = z, a3 = z;
             gen_dot4(a0, a1, a2, a3, W + (size_t)mo * K16 * 64, W + (size_t)m1 * K16 * 64, W + (size_t)m2 * K16 * 64, W + (size_t)m3 * K16 * 64,
-                     nullptr, 0, B, B, K16);
+                     nullptr, 0, B, B, K16, ln);
             epi(mo, a0);
             if (mo + 1 < M16) epi(m1, a1);
             if (mo + 2 < M16) epi(m2, a2);
@@ -497,7 +562,7 @@ __device__ __forceinline__ void gen_matvec(const f32x4* __restrict__ W /*lane-of
         for (int mo = 0; mo < M16; mo += 2) {
             const int m1 = mo + 1 < M16 ? mo + 1 : mo;
             f32x4 a0 = z, a1 = z;
-            gen_dot(a0, a1, W + (size_t)mo * K16 * 64, W + (size_t)m1 * K16 * 64, nullptr, 0, B, B, K16);
+            gen_dot(a0, a1, W + (size_t)mo * K16 * 64, W + (size_t)m1 * K16 * 64, nullptr, 0, B, B, K16, ln);
             epi(mo, a0);
             if (mo + 1 < M16) epi(m1, a1);
         }
@@ -516,7 +581,8 @@ __global__ __launch_bounds__(512) void gen_gru_bwd_kernel(const f32x4* __restric
                                                           const f32x4* __restrict__ S, const f32x4* __restrict__ DY /*[tiles][35][2 H16][64]*/,
                                                           f32x4* __restrict__ DA, int n_tiles, int H16) {
     extern __shared__ f32x4 gen_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dir = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, dir = blockIdx.y;
+    const unsigned ln = lane;
     const int waves = blockDim.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * waves + wave;
     if (tile >= n_tiles) return;
@@ -524,7 +590,7 @@ __global__ __launch_bounds__(512) void gen_gru_bwd_kernel(const f32x4* __restric
     f32x4* dac = dh + (size_t)H16 * 64;
     f32x4* dar = dac + (size_t)H16 * 64;
     f32x4* dau = dar + (size_t)H16 * 64;
-    const f32x4* WcT = WT + ((size_t)dir * 3 * H16 * H16) * 64 + lane;
+    const f32x4* WcT = WT + ((size_t)dir * 3 * H16 * H16) * 64;            // uniform: the lane is added at the access
     const f32x4* WgT = WcT + (size_t)H16 * H16 * 64;
     for (int mo = 0; mo < H16; ++mo) dh[mo * 64] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < CF_T; ++s) {
@@ -553,8 +619,8 @@ __global__ __launch_bounds__(512) void gen_gru_bwd_kernel(const f32x4* __restric
             dh[mo * 64] = dh[mo * 64] + drh * r;
             dar[mo * 64] = ar;
             da[mo * 64] = ar;
-        });
-        gen_matvec(WgT, H16, 2 * H16, dar, [&](int mo, const f32x4& g) { dh[mo * 64] = dh[mo * 64] + g; });
+        }, ln);
+        gen_matvec(WgT, H16, 2 * H16, dar, [&](int mo, const f32x4& g) { dh[mo * 64] = dh[mo * 64] + g; }, ln);
     }
 }
 
