@@ -8,6 +8,10 @@
 // Included by catfish_hip.hip (needs f32x4, MFMA16, CF_T, CF_TILE, CF_GATE_SCALE, CF_CAND_SCALE).
 #pragma once
 
+#ifndef CF_GEN_LOCKSTEP
+#define CF_GEN_LOCKSTEP 1      // barrier per output-tile group in the biGRU kernels (see gen_gru_kernel)
+#endif
+
 // A pack of a matrix with K inputs (K16 blocks of 16) and M outputs (M16 tiles): f32x4 P[(mo * K16 + kb) * 64 + lane] =
 // W[in = 16 kb + 4 (lane >> 4) + i][out = 16 mo + (lane & 15)], i = 0..3: component i is the A operand of the MFMA whose B
 // operand is register i of input tile kb (lane quarter q of that register carries feature 16 kb + 4 q + i).
@@ -204,40 +208,40 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const f32x4* __restrict__
     for (int64_t task = (int64_t)blockIdx.x * 4 + wave; task < n_tasks; task += (int64_t)gridDim.x * 4) {
         const int64_t tile = task / CF_T;
         const int t = (int)(task - tile * CF_T);
-        for (int mo = 0; mo < Co16; mo += 2) {
-            const int m1 = mo + 1 < Co16 ? mo + 1 : mo;
-            f32x4 acc0 = Bv[mo * 64 + lane], acc1 = Bv[m1 * 64 + lane];
+        auto finish = [&](int mo, f32x4 acc) {
+            if (relu & 1) {                                                   // relu(BN(conv)), resnet_class.py:66,71,76
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+            }
+            if (R) acc += R[((tile * CF_T + t) * Co16 + mo) * 64 + lane];     // + shortcut, resnet_class.py:79
+            if (relu & 2) {                                                   // relu(o + shortcut), resnet_class.py:80
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+            }
+            Y[((tile * CF_T + t) * Co16 + mo) * 64 + lane] = acc;
+        };
+        const int step = Co16 >= 4 ? 4 : 2;                                   // output tiles per pass: four MFMA chains sharing the B operand
+        for (int mo = 0; mo < Co16; mo += step) {
+            const int m1 = mo + 1 < Co16 ? mo + 1 : mo, m2 = mo + 2 < Co16 ? mo + 2 : mo, m3 = mo + 3 < Co16 ? mo + 3 : mo;
+            f32x4 acc0 = Bv[mo * 64 + lane], acc1 = Bv[m1 * 64 + lane], acc2 = Bv[m2 * 64 + lane], acc3 = Bv[m3 * 64 + lane];
             for (int tap = 0; tap < taps; ++tap) {
                 const int tt = t + tap - (taps >> 1);
                 if (tt < 0 || tt >= CF_T) continue;                           // zero padding at the window edges
                 const f32x4* xb = X + ((tile * CF_T + tt) * Ki16) * 64;       // uniform pointers, lane added at the access
-                const f32x4* wa = W + ((int64_t)(tap * Co16 + mo) * Ki16) * 64;
-                const f32x4* wb = W + ((int64_t)(tap * Co16 + m1) * Ki16) * 64;
-                gen_dot(acc0, acc1, wa, wb, xb, Ki16, nullptr, nullptr, 0, ln);
+                const f32x4* wt = W + ((int64_t)tap * Co16 * Ki16) * 64;
+                if (step == 4)
+                    gen_dot4(acc0, acc1, acc2, acc3, wt + (int64_t)mo * Ki16 * 64, wt + (int64_t)m1 * Ki16 * 64, wt + (int64_t)m2 * Ki16 * 64,
+                             wt + (int64_t)m3 * Ki16 * 64, xb, Ki16, nullptr, nullptr, 0, ln);
+                else
+                    gen_dot(acc0, acc1, wt + (int64_t)mo * Ki16 * 64, wt + (int64_t)m1 * Ki16 * 64, xb, Ki16, nullptr, nullptr, 0, ln);
             }
-            f32x4* y0 = Y + ((tile * CF_T + t) * Co16 + mo) * 64 + lane;
-            f32x4* y1 = Y + ((tile * CF_T + t) * Co16 + m1) * 64 + lane;
-            if (relu & 1) {                                                   // relu(BN(conv)), resnet_class.py:66,71,76
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc0[j] = fmaxf(acc0[j], 0.f); acc1[j] = fmaxf(acc1[j], 0.f); }
-            }
-            if (R) {                                                          // + shortcut, resnet_class.py:79
-                acc0 += R[((tile * CF_T + t) * Co16 + mo) * 64 + lane];
-                acc1 += R[((tile * CF_T + t) * Co16 + m1) * 64 + lane];
-            }
-            if (relu & 2) {                                                   // relu(o + shortcut), resnet_class.py:80
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc0[j] = fmaxf(acc0[j], 0.f); acc1[j] = fmaxf(acc1[j], 0.f); }
-            }
-            *y0 = acc0;
-            if (m1 != mo) *y1 = acc1;
+            finish(mo, acc0);
+            if (mo + 1 < Co16) finish(m1, acc1);
+            if (step == 4 && mo + 2 < Co16) finish(m2, acc2);
+            if (step == 4 && mo + 3 < Co16) finish(m3, acc3);
         }
     }
 }
-
-#ifndef CF_GEN_LOCKSTEP
-#define CF_GEN_LOCKSTEP 1
-#endif
 
 // ---- one bidirectional GRU layer (rnn_class.py:142-148,165-175; GRUCell wiring of the checkpoint's graph) -----------------
 // One wave = one 16-window tile of one direction, 35 serial steps.  Per step: r = sigmoid(Wr [x, h] + br), two output tiles
