@@ -124,3 +124,51 @@ def test_adam_step_count_survives_a_long_run():
     gone = TFOptimizer(p, "Adam", 0.1)
     gone.load_state_tf({"optimizer/beta1_power": np.float32(0.0), "optimizer/beta2_power": np.float32(0.0)})
     assert float(gone.t) >= 1e5
+
+
+def test_anysize_pack_maps_follow_the_fragment_formula():
+    """catfish_amd/anysize_train.pack_maps (vectorised numpy) against the definition of the A-fragment layout written as plain
+    loops (include/catfish_hip.h, cf_gru_anysize_train_forward): component i of lane l of block (mo, kb) holds
+    W[in = 16 kb + 4 (l >> 4) + i][out = 16 mo + (l & 15)], x rows zero-padded to whole blocks, r / u scaled by -log2 e and the
+    candidate by 2 log2 e; the transposed packs of the backward chain likewise."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd import anysize_train as at
+    h, cin = 32, 20                                   # cin not a multiple of 16: exercises the zero padding
+    rng = np.random.default_rng(0)
+    wg = rng.normal(size=(cin + h, 2 * h)).astype(np.float32)
+    wc = rng.normal(size=(cin + h, h)).astype(np.float32)
+    bg = rng.normal(size=2 * h).astype(np.float32)
+    bc = rng.normal(size=h).astype(np.float32)
+    src = torch.from_numpy(np.concatenate([wg.reshape(-1), wc.reshape(-1), bg, bc, np.zeros(1, np.float32)]))
+    w_idx, w_scale, b_idx, b_scale, wt_idx = at.pack_maps(h, cin, "cpu")
+    h16, kbx = h // 16, (cin + 15) // 16
+    kb_all = kbx + h16
+    got_w = (src[w_idx] * w_scale).numpy().reshape(3, h16, kb_all, 64, 4)
+    got_b = (src[b_idx] * b_scale).numpy().reshape(3, h16, 64, 4)
+    got_t = src[wt_idx].numpy()
+    gate_scale, cand_scale = -1.4426950408889634, 2 * 1.4426950408889634
+    for gate in range(3):
+        mat = wg[:, :h] if gate == 0 else (wg[:, h:] if gate == 1 else wc)
+        bias = bg[:h] if gate == 0 else (bg[h:] if gate == 1 else bc)
+        sc = gate_scale if gate < 2 else cand_scale
+        for mo in range(h16):
+            for lane in range(64):
+                for j in range(4):
+                    assert got_b[gate, mo, lane, j] == np.float32(bias[16 * mo + 4 * (lane >> 4) + j] * np.float32(sc))
+                for kb in range(kb_all):
+                    for i in range(4):
+                        inn, out = 16 * kb + 4 * (lane >> 4) + i, 16 * mo + (lane & 15)
+                        if inn < 16 * kbx:
+                            want = mat[inn, out] if inn < cin else 0.0
+                        else:
+                            want = mat[cin + inn - 16 * kbx, out]
+                        assert got_w[gate, mo, kb, lane, i] == np.float32(np.float32(want) * np.float32(sc)), (gate, mo, kb, lane, i)
+    wct = got_t[:h16 * h16 * 256].reshape(h16, h16, 64, 4)
+    wgt = got_t[h16 * h16 * 256:].reshape(h16, 2 * h16, 64, 4)
+    for mo in range(h16):
+        for lane in range(0, 64, 7):
+            for i in range(4):
+                for kb in range(h16):
+                    assert wct[mo, kb, lane, i] == wc[cin + 16 * mo + (lane & 15), 16 * kb + 4 * (lane >> 4) + i]
+                for kb in range(2 * h16):
+                    assert wgt[mo, kb, lane, i] == wg[cin + 16 * mo + (lane & 15), 16 * kb + 4 * (lane >> 4) + i]
