@@ -198,40 +198,41 @@ class RNN(object):
         confidences = self.engine.infer_host(np.asarray(input_x))
         return np.reshape(confidences, (-1)).astype(float)
 
-    def test_network(self, test_x, test_y, read_name, file_path, padding_size, threshold=0.5):
-        """rnn_class.py:222-261: predictions + accuracy/loss + running confusion counters."""
+    def score_windows(self, windows):
+        """[N,35(,1)] windows -> (probabilities, logits), float32 [N*35] each, from ONE forward pass: ``self.predictions``
+        (rnn_class.py:84) and the pre-sigmoid ``self.logits`` (rnn_class.py:178-183) the loss is defined on.  N is
+        unbounded (the library walks it in passes), so a whole validation round is one call."""
         self._require_engine()
-        probs32, logits32 = self.engine.infer_host(np.asarray(test_x), return_logits=True)
-        confidences = np.reshape(probs32, (-1)).astype(float)
-        pred_vals = (confidences >= threshold).astype(np.int64)
-        test_labels = np.asarray(test_y).reshape(-1)
-        # accuracy: tf.equal(tf.round(p), y) (rnn_class.py:85-86)
-        test_acc = float(np.mean(np.round(confidences) == test_labels))
-        # loss: tf.losses.sigmoid_cross_entropy evaluates the LOGITS (rnn_class.py:74-79):
-        # mean(max(z, 0) - z*y + log1p(exp(-|z|))); probabilities saturate in fp32 and cannot reproduce it
-        test_loss = sigmoid_cross_entropy_from_logits(logits32.astype(np.float64), test_labels)
-        true_pos, false_pos, true_neg, false_neg = metrics.confusion_matrix(test_labels, pred_vals)
-        self.tp += true_pos
-        self.fp += false_pos
-        self.tn += true_neg - padding_size
-        self.fn += false_neg
-        return test_acc, test_loss
+        return self.engine.infer_host(np.asarray(windows), return_logits=True)
+
+    def test_network(self, test_x, test_y, read_name, file_path, padding_size, threshold=0.5):
+        """rnn_class.py:222-261: accuracy and loss of one padded read + running confusion counters (the per-read
+        form of the surface; ``train_validate.validate`` scores a whole round in one packed call instead)."""
+        from .train_validate import score_validation_batch
+        probs32, logits32 = self.score_windows(test_x)
+        y = np.asarray(test_y, dtype=np.float64).reshape(-1)
+        acc, loss, counts = score_validation_batch(probs32, logits32, y, np.array([0, y.size]),
+                                                   np.array([padding_size]), threshold)
+        self.tp, self.fp, self.tn, self.fn = (have + new for have, new in
+                                              zip((self.tp, self.fp, self.tn, self.fn), counts))
+        return float(acc[0]), float(loss[0])
 
     def evaluate(self, set_x, set_y):
         """``sess.run([self.accuracy, self.loss], ...)`` (networks/train_validate.py:162; rnn_class.py:74-88) on the
         inference graph: (accuracy, loss) of one batch without touching the confusion counters."""
-        self._require_engine()
-        probs32, logits32 = self.engine.infer_host(np.asarray(set_x), return_logits=True)
+        probs32, logits32 = self.score_windows(set_x)
         labels = np.asarray(set_y).reshape(-1)
         acc = float(np.mean(np.round(probs32.astype(float)) == labels))
         return acc, sigmoid_cross_entropy_from_logits(logits32.astype(np.float64), labels)
 
     def train_network(self, train_x, train_y, step):
-        """rnn_class.py:201-210: one optimizer step on a batch (PyTorch-ROCm autograd, TF update rules).
+        """rnn_class.py:201-210: one optimizer step on a batch (TF-1 update rules, dropout on the biGRU outputs).
 
-        The forward/backward of the training step runs in torch (BASELINE config 5: "Adam in
-        PyTorch-ROCm"); the updated weights are pushed back into the HIP engine lazily, at the
-        next ``infer``.  TensorBoard summaries (the reference's second forward) are not written.
+        On a GPU the whole step -- forward, loss, backward, optimizer, weight re-tiling -- runs on HIP kernels through
+        the C ABI (``training.Trainer`` -> ``native_step.py`` for the shipped 64 / 32 geometry, ``anysize_train.py``
+        for other sizes); the torch restatement is the CPU mode and the test reference.  The inference engine picks
+        the updated weights up lazily, at the next ``infer``.  TensorBoard summaries (the reference's second forward,
+        :206-208) are not written.
         """
         if self.weights is None:
             raise RuntimeError("network has no weights: call restore_network() or initialize_network() first")

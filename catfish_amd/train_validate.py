@@ -25,12 +25,17 @@ from .neural_network import build_model as _build_model
 
 
 def reshape_input(data, window, n_inputs):
-    """networks/train_validate.py:15-31 (a failed reshape is printed and swallowed there; same here)."""
+    """networks/train_validate.py:15-31: ``[-1, window, n_inputs]`` view of the data.  Data that does not fill whole
+    windows is NOT an error there: two lengths are printed and the data comes back as it was; same here."""
     try:
-        data = np.reshape(data, (-1, window, n_inputs))
-    except ValueError:
-        print(len(data))
-        print(len(data[0]))
+        flat = np.asarray(data)
+        fits = flat.size % (window * n_inputs) == 0
+    except ValueError:                                     # ragged rows
+        fits = False
+    if fits:
+        return flat.reshape(-1, window, n_inputs)
+    for what in (data, data[0]):
+        print(len(what))
     return data
 
 
@@ -40,14 +45,12 @@ def build_model(network_type, **kwargs):
 
 
 def padding(data, window=35, n_input=1):
-    """networks/train_validate.py:50-63: pad to a multiple of the window; unlike catfish/infer.py:32-36 an exact
-    multiple gets NO extra window here (padding_size = 0)."""
-    if not (len(data) / window).is_integer():
-        padding_size = window - (len(data) - (len(data) // window * window))
-        data = np.hstack((data, np.array(padding_size * [0])))
-    else:
-        padding_size = 0
-    return reshape_input(data, window, n_input), padding_size
+    """networks/train_validate.py:51-64: integer zeros up to the next multiple of the window -> (windows, how many).
+    Unlike catfish/infer.py:32-36 an exact multiple gets NO extra window here."""
+    tail = -len(data) % window
+    if tail:
+        data = np.hstack((data, np.zeros(tail, dtype=np.int64)))
+    return reshape_input(data, window, n_input), tail
 
 
 def generate_random_hyperparameters(network_type, learning_rate_min=-4, learning_rate_max=0,
@@ -55,27 +58,33 @@ def generate_random_hyperparameters(network_type, learning_rate_min=-4, learning
                                     n_layers_min=1, n_layers_max=6, batch_size_list=(128, 256, 512),
                                     dropout_min=0.2, dropout_max=0.8, n_layers_res_min=1, n_layers_res_max=12,
                                     size_layers_res_list=(16, 32, 64, 128, 256)):
-    """networks/train_validate.py:66-111, draw for draw (numpy's global generator, same call order).
+    """networks/train_validate.py:66-111: one random-search draw from numpy's GLOBAL generator, in the reference's
+    call order (so a seeded run draws the same network): learning-rate exponent, optimizer, layer size, depth, batch
+    size, keep probability, and for ResNetRNN a residual depth that is drawn and then DROPPED -- the reference stores
+    ``n_layers`` under ``n_layers_res`` (:109) -- and the residual width.
 
-    Kept quirk: the reference stores ``n_layers`` under ``n_layers_res`` (:109) and discards its own draw.
     Every draw builds: the shipped geometry (``layer_size`` 64 / ``layer_size_res`` 32, any depth) runs on the tuned HIP
     kernels and trains natively; other sizes infer on the any-size HIP kernels (csrc/generic.hpp) and train through torch
     autograd with the recurrence on the same kernel family (anysize_train.py).
     """
-    learning_rate = 10 ** np.random.randint(learning_rate_min, learning_rate_max)
-    optimizer = np.random.choice(list(optimizer_list))
-    layer_size = np.random.choice(list(layer_size_list))
-    n_layers = np.random.randint(n_layers_min, n_layers_max)
-    batch_size = np.random.choice(list(batch_size_list))
-    dropout = round(np.random.uniform(dropout_min, dropout_max), 1)
-    hpm_dict = {"batch_size": int(batch_size), "optimizer_choice": str(optimizer), "learning_rate": float(learning_rate),
-                "layer_size": int(layer_size), "n_layers": int(n_layers), "keep_prob": dropout}
+    rs = np.random
+    plan = [("learning_rate", lambda: float(10 ** rs.randint(learning_rate_min, learning_rate_max))),
+            ("optimizer_choice", lambda: str(rs.choice(list(optimizer_list)))),
+            ("layer_size", lambda: int(rs.choice(list(layer_size_list)))),
+            ("n_layers", lambda: int(rs.randint(n_layers_min, n_layers_max))),
+            ("batch_size", lambda: int(rs.choice(list(batch_size_list)))),
+            ("keep_prob", lambda: round(rs.uniform(dropout_min, dropout_max), 1))]
     if network_type == "ResNetRNN":
-        np.random.randint(n_layers_res_min, n_layers_res_max)          # drawn and dropped, as in the reference
-        size_layers_res = np.random.choice(list(size_layers_res_list))
-        hpm_dict["layer_size_res"] = int(size_layers_res)
-        hpm_dict["n_layers_res"] = int(n_layers)
-    return hpm_dict
+        plan += [(None, lambda: rs.randint(n_layers_res_min, n_layers_res_max)),
+                 ("layer_size_res", lambda: int(rs.choice(list(size_layers_res_list))))]
+    drawn = {}
+    for key, draw in plan:
+        value = draw()
+        if key is not None:
+            drawn[key] = value
+    if "layer_size_res" in drawn:
+        drawn["n_layers_res"] = drawn["n_layers"]
+    return drawn
 
 
 # --------------------------------------------------------------------------- training databases
@@ -176,124 +185,209 @@ def synthetic_example_db(n_reads=8, read_len=20000, seed=0):
     return WindowExampleDb(pos, neg, seed=seed)
 
 
-# --------------------------------------------------------------------------- train / validate
+# --------------------------------------------------------------------------- training loop
+def _append(path, text):
+    with open(path, "a+") as fh:
+        fh.write(text)
+
+
+def _checkpoint_round(network, step, batch_x, batch_y, report, validation):
+    """What the reference does at a checkpoint step (networks/train_validate.py:154-175): save, score the batch just
+    trained on, run one round of validation; the report lines go to ``report`` in that order."""
+    network.save_network_to_model_path(step)
+    saved = "Saved checkpoint at step {}\n".format(step)
+    print(saved)
+    _append(report, "\n" + saved)
+    clock = datetime.datetime.now()
+    # the reference feeds the TRAINING keep_prob here (:163), so its two numbers carry dropout noise; the
+    # deterministic inference pass is reported instead
+    batch_acc, batch_loss = network.evaluate(batch_x, batch_y)
+    print("Validated in {}".format(datetime.datetime.now() - clock))
+    _append(report, "\nTraining accuracy: {}\nTraining loss: {}\n".format(batch_acc, batch_loss))
+    clock = datetime.datetime.now()
+    _acc, precision, recall = validate(network, *validation)
+    print("Validated in {}".format(datetime.datetime.now() - clock))
+    _append(report, "Validation precision: {}\nValidation recall: {}\n".format(precision, recall))
+    return batch_acc
+
+
 def train_and_validate(network, db, training_nr, squiggles, max_seq_length, file_path, validation_start, max_number,
                        checkpoint_every=10000):
-    """networks/train_validate.py:114-185: ``training_nr // batch_size`` optimizer steps on balanced batches; at the
-    last step and every ``checkpoint_every`` (10 000 in the reference) steps: checkpoint, training metrics of the
-    current batch, one round of validation.  Returns the last training accuracy."""
+    """networks/train_validate.py:114-185.  ``training_nr // batch_size`` optimizer steps on balanced batches from
+    ``db.get_training_set``; after the last step and after every ``checkpoint_every``-th (10 000 in the reference):
+    checkpoint + batch metrics + one validation round.  Report text appended to ``file_path + ".txt"`` as the
+    reference writes it.  Returns the last batch accuracy (None when no step ran; the reference fails on its unbound
+    local there)."""
+    report = file_path + ".txt"
+    steps = training_nr // network.batch_size
+    seen = steps * network.batch_size
+    banner = "\nTraining on {} examples in {} batches\n".format(seen, steps)
     print("Start training at {}".format(datetime.datetime.now()))
-    n_examples = training_nr // network.batch_size * network.batch_size
-    n_batches = n_examples // network.batch_size
-    print("\nTraining on {} examples in {} batches\n".format(n_examples, n_batches))
-    train_acc = None
-    with open(file_path + ".txt", "a+") as dest:
-        dest.write("\nTraining on {} examples in {} batches\n".format(n_examples, n_batches))
-        step = 0
-        positives = 0
-        for _b in range(n_batches):
-            data, labels, pos = db.get_training_set(network.batch_size, ratio=2)
-            positives += pos
-            set_x = reshape_input(data, network.window, network.n_inputs)
-            set_y = reshape_input(labels, network.window, network.n_outputs)
-            step += 1                                                           # step is per batch
-            network.train_network(set_x, set_y, step)
-            if step == n_batches or step % checkpoint_every == 0:
-                network.save_network_to_model_path(step)
-                print("Saved checkpoint at step {}\n".format(step))
-                dest.write("\nSaved checkpoint at step {}\n".format(step))
-                # training performance on the current batch (the reference evaluates accuracy and loss with the
-                # training keep_prob fed, :162; here the deterministic inference graph is used)
-                t1 = datetime.datetime.now()
-                train_acc, train_loss = network.evaluate(set_x, set_y)
-                print("Validated in {}".format(datetime.datetime.now() - t1))
-                dest.write("\nTraining accuracy: {}\n".format(train_acc))
-                dest.write("Training loss: {}\n".format(train_loss))
-                t1 = datetime.datetime.now()
-                dest.flush()
-                _val_acc, whole_precision, whole_recall = validate(network, squiggles, max_seq_length, file_path,
-                                                                   validation_start, max_number)
-                print("Validated in {}".format(datetime.datetime.now() - t1))
-                dest.write("Validation precision: {}\n".format(whole_precision))
-                dest.write("Validation recall: {}\n".format(whole_recall))
-        try:
-            train_hp = positives / (network.window * n_examples)
-        except ZeroDivisionError:
-            train_hp = 0
-        dest.write("\nTraining set had {:.2%} HPs\n".format(train_hp))
-        dest.write("\nFinished training!\n\n")
-    return train_acc
+    print(banner)
+    _append(report, banner)
+    validation = (squiggles, max_seq_length, file_path, validation_start, max_number)
+    hp_labels = 0
+    batch_acc = None
+    for step in range(1, steps + 1):
+        windows, labels, n_pos = db.get_training_set(network.batch_size, ratio=2)
+        hp_labels += n_pos
+        batch_x = reshape_input(windows, network.window, network.n_inputs)
+        batch_y = reshape_input(labels, network.window, network.n_outputs)
+        network.train_network(batch_x, batch_y, step)
+        if step == steps or step % checkpoint_every == 0:
+            if step == steps - 1:
+                print("This was the final checkpoint\n")          # the reference's off-by-one message (:158)
+            batch_acc = _checkpoint_round(network, step, batch_x, batch_y, report, validation)
+    share = hp_labels / (network.window * seen) if seen else 0
+    _append(report, "\nTraining set had {:.2%} HPs\n".format(share) + "\nFinished training!\n\n")
+    return batch_acc
+
+
+# --------------------------------------------------------------------------- validation: select, ONE packed launch, sums
+_VALIDATION_REPORT = (
+    "\n---NEXT ROUND OF VALIDATION---"
+    "\nAverage performance of validation set:\n"
+    "\tAccuracy: {mean_acc:.2%}\n"
+    "\tLoss: {mean_loss:.4f}"
+    "\nPerformance over whole set: \n"
+    "\tDetected {tp} true positives, {fp} false positives, {tn} true negatives, {fn} false negatives in total.\n"
+    "\tTrue number of HPs: {hp} \tTrue percentage: {hp_share:.2%}\t Predicted percentage HPs: {called_share:.2%}\n"
+    "\tAccuracy: {acc:.2%}"
+    "\n\tPrecision: {precision:.2%}\n\tRecall: {recall:.2%}"
+    "\t\nF1 score: {f1:.4f}"
+    "{closing}")
+_VALIDATION_CLOSING = "\nFinished validation of model {} on {} raw signals of average length {}."
+
+
+def select_validation_stretches(squiggles, window, max_seq_length, validation_start, max_number, loader=load_npz):
+    """Which samples one validation round scores (networks/train_validate.py:214-249), in file order.
+
+    ``validation_start``: "complete" = whole reads; an int = the stretch ``[start, start + n)``; "random" = a stretch
+    at ``random.randint(0, len - n)`` (Python's global generator, one draw per read that is long enough, so a seeded
+    run picks the reference's stretches); ``n`` = ``max_seq_length`` rounded down to whole windows.  Reads shorter
+    than the stretch are skipped; the selection stops once ``max_number`` reads are in.
+    -> (signals, labels): two lists of 1-D arrays."""
+    whole = validation_start == "complete"
+    if not whole and validation_start != "random" and type(validation_start) != int:
+        raise ValueError("validation_start must be an int, 'random' or 'complete'")
+    n = max_seq_length // window * window
+    signals, labels = [], []
+    for path in squiggles:
+        raw, lab = loader(path)
+        if not whole:
+            room = len(raw) - n - (0 if validation_start == "random" else validation_start)
+            if room < 0:
+                continue
+            first = random.randint(0, room) if validation_start == "random" else validation_start
+            raw, lab = raw[first:first + n], lab[first:first + n]
+        signals.append(np.asarray(raw))
+        labels.append(np.asarray(lab))
+        if len(signals) >= max_number:
+            break
+    return signals, labels
+
+
+def pack_validation_windows(signals, labels, window):
+    """All stretches as one window-major batch: x float32 [sum N_i, window, 1], y float64 [sum N_i * window], the first
+    packed sample of every read (int64 [n_reads + 1]) and each read's zero tail.  The tail rule is the training
+    driver's ``padding`` (:51-64): an exact multiple of the window gets none."""
+    lengths = np.array([len(s) for s in signals], dtype=np.int64)
+    n_win = -(-lengths // window)
+    tails = n_win * window - lengths
+    bounds = np.zeros(len(signals) + 1, dtype=np.int64)
+    np.cumsum(n_win * window, out=bounds[1:])
+    x = np.zeros(int(bounds[-1]), dtype=np.float32)
+    y = np.zeros(int(bounds[-1]), dtype=np.float64)
+    for b, s, l in zip(bounds[:-1].tolist(), signals, labels):
+        x[b:b + len(s)] = s
+        y[b:b + len(l)] = l
+    return x.reshape(-1, window, 1), y, bounds, tails
+
+
+def score_validation_batch(probs32, logits32, y, bounds, tails, threshold=0.5):
+    """Per-read accuracy / loss and whole-batch confusion counts from ONE packed forward pass
+    (what rnn_class.py:222-261 computes read by read):
+
+    * accuracy_i = mean(round_half_even(p) == y) over the read's padded windows -- ``tf.round`` sends p = 0.5 to 0
+      (rnn_class.py:85) -- as float32, an exact count divided once;
+    * loss_i = mean sigmoid cross-entropy of the LOGITS (rnn_class.py:74-79), summed in double, float32;
+    * counts: prediction = ``p >= threshold`` (so p = 0.5 counts as a call); a called sample is a true positive when
+      its label is 1 and a false positive otherwise -- zero tails included --, an un-called one a true negative when
+      its label is 0 and a false negative otherwise; then every tail sample is taken out of the true negatives whether
+      or not it was one (rnn_class.py:245-249)."""
+    p = np.asarray(probs32, dtype=np.float64).reshape(-1)
+    z = np.asarray(logits32, dtype=np.float64).reshape(-1)
+    called = p >= threshold
+    counts = (int(np.count_nonzero(called & (y == 1))), int(np.count_nonzero(called & (y != 1))),
+              int(np.count_nonzero(~called & (y == 0))) - int(tails.sum()), int(np.count_nonzero(~called & (y != 0))))
+    right = np.concatenate(([0], np.cumsum(np.round(p) == y)))
+    sizes = np.diff(bounds)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        acc = (right[bounds[1:]] - right[bounds[:-1]]).astype(np.float32) / sizes.astype(np.float32)
+        ce = np.maximum(z, 0.0) - z * y + np.log1p(np.exp(-np.abs(z)))
+        loss = np.array([np.sum(ce[a:b]) for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist())]) / sizes
+    return acc, loss.astype(np.float32), counts
 
 
 def validate(network, squiggles, max_seq_length, file_path, validation_start="random", max_number=856):
-    """networks/train_validate.py:188-295: per NPZ read a stretch of ``max_seq_length`` samples (fixed start, random
-    start, or the "complete" read) through ``network.test_network``; report text appended to ``<basename>.txt`` in the
-    current directory exactly as the reference writes it.  Returns (accuracy, precision, recall) over the whole set
-    and resets the network's confusion counters."""
-    total_length = 0
-    accuracy = 0
-    loss = 0
-    valid_reads = 0
+    """networks/train_validate.py:188-295 as one packed launch.
+
+    The reference pushes every read through ``test_network`` (one ``sess.run`` each, up to 856 per round); windows are
+    independent, so here the selected stretches of ALL reads form one ``[sum N_i, 35, 1]`` batch that goes through
+    ``network.score_windows`` once, and the per-read numbers come out of array sums over the read boundaries.  Same
+    report (appended to ``<basename of file_path>.txt`` in the current directory), prints, return value
+    ``(accuracy, precision, recall)`` over the whole set, and the same bookkeeping: counts are added to the
+    network's running ``tp/fp/tn/fn`` and those are reset afterwards.
+
+    Kept behaviour of the loop being replaced: the read that reaches ``max_number`` is scored and counted but its
+    accuracy / loss are left out of the averages, which still divide by the number of reads (:248-256); no read
+    selected -> ZeroDivisionError."""
     print("Max length is {}".format(max_seq_length))
     print("Validation start is {}".format(validation_start))
-    file_path = file_path.split("/")[-1]
-    for squig in squiggles:
-        data_sq, labels_sq = load_npz(squig)
-        if validation_start == "complete":
-            total_length += len(data_sq)
-        else:
-            max_seq_length = max_seq_length // network.window * network.window
-            if type(validation_start) == int:
-                if len(data_sq) >= validation_start + max_seq_length:
-                    start_val = validation_start
-                else:
-                    continue
-            elif validation_start == "random":
-                if len(data_sq) >= max_seq_length:
-                    start_val = random.randint(0, len(data_sq) - max_seq_length)
-                else:
-                    continue
-            labels_sq = labels_sq[start_val: start_val + max_seq_length]
-            data_sq = data_sq[start_val: start_val + max_seq_length]
-            total_length += max_seq_length
-        read_name = os.path.basename(squig).split(".npz")[0]
-        valid_reads += 1
-        set_x, padding_size = padding(data_sq, network.window, network.n_inputs)
-        set_y, _ = padding(labels_sq, network.window, network.n_inputs)
-        sgl_acc, sgl_loss = network.test_network(set_x, set_y, read_name, file_path, padding_size)
-        if valid_reads >= max_number:
-            break                                   # kept: the last read's accuracy / loss are not added (:253-260)
-        accuracy += sgl_acc
-        loss += sgl_loss
+    signals, labels = select_validation_stretches(squiggles, network.window, max_seq_length, validation_start,
+                                                  max_number)
+    n_reads = len(signals)
+    n_samples = sum(len(s) for s in signals)
+    if n_reads == 0:
+        raise ZeroDivisionError("validation selected no read")
+    x, y, bounds, tails = pack_validation_windows(signals, labels, network.window)
+    probs, logits = network.score_windows(x)
+    acc, loss, counts = score_validation_batch(probs, logits, y, bounds, tails)
+    averaged = n_reads - 1 if n_reads >= max_number else n_reads
+    acc_sum = loss_sum = 0
+    for a, l in zip(acc[:averaged].tolist(), loss[:averaged].tolist()):      # doubles holding float32 values, in order
+        acc_sum += a
+        loss_sum += l
+    network.tp, network.fp, network.tn, network.fn = (have + new for have, new in
+                                                      zip((network.tp, network.fp, network.tn, network.fn), counts))
+    tp, fp, tn, fn = network.tp, network.fp, network.tn, network.fn
+    whole_acc = metrics.calculate_accuracy(tp, fp, tn, fn)
+    precision, recall = metrics.precision_recall(tp, fp, fn)
+    closing = _VALIDATION_CLOSING.format(network.model_type, n_reads, n_samples / n_reads)
+    _append(file_path.split("/")[-1] + ".txt", _VALIDATION_REPORT.format(
+        mean_acc=acc_sum / n_reads, mean_loss=loss_sum / n_reads, tp=tp, fp=fp, tn=tn, fn=fn, hp=tp + fn,
+        hp_share=(tp + fn) / n_samples, called_share=(tp + fp) / n_samples, acc=whole_acc, precision=precision,
+        recall=recall, f1=metrics.f1(precision, recall), closing=closing))
+    print(closing)
+    network.tp = network.fp = network.tn = network.fn = 0
+    print("Validation accuracy: ", whole_acc)
+    print("Validation loss: ", loss_sum / n_reads)
+    return whole_acc, precision, recall
 
-    whole_accuracy = metrics.calculate_accuracy(network.tp, network.fp, network.tn, network.fn)
-    whole_precision, whole_recall = metrics.precision_recall(network.tp, network.fp, network.fn)
-    whole_f1 = metrics.f1(whole_precision, whole_recall)
-    with open(file_path + ".txt", "a+") as dest:
-        dest.write("\n---NEXT ROUND OF VALIDATION---")
-        dest.write("\nAverage performance of validation set:\n")
-        dest.write("\tAccuracy: {:.2%}\n".format(accuracy / valid_reads))
-        dest.write("\tLoss: {0:.4f}".format(loss / valid_reads))
-        dest.write("\nPerformance over whole set: \n")
-        dest.write("\tDetected {} true positives, {} false positives, {} true negatives, {} false negatives in total.\n".
-                   format(network.tp, network.fp, network.tn, network.fn))
-        dest.write("\tTrue number of HPs: {} \tTrue percentage: {:.2%}\t Predicted percentage HPs: {:.2%}\n".
-                   format(network.tp + network.fn, (network.tp + network.fn) / (total_length),
-                          (network.tp + network.fp) / (total_length)))
-        dest.write("\tAccuracy: {:.2%}".format(whole_accuracy))
-        dest.write("\n\tPrecision: {:.2%}\n\tRecall: {:.2%}".format(whole_precision, whole_recall))
-        dest.write("\t\nF1 score: {0:.4f}".format(whole_f1))
-        dest.write("\nFinished validation of model {} on {} raw signals of average length {}.".format(
-            network.model_type, valid_reads, total_length / valid_reads))
-    print("\nFinished validation of model {} on {} raw signals of average length {}.".format(
-        network.model_type, valid_reads, total_length / valid_reads))
-    network.tp = 0
-    network.fn = 0
-    network.tn = 0
-    network.fp = 0
-    print("Validation accuracy: ", whole_accuracy)
-    print("Validation loss: ", loss / valid_reads)
-    return whole_accuracy, whole_precision, whole_recall
+
+_USAGE = ("The following arguments should be provided in this order:\n"
+          "\t-network type\n\t-path to training db"
+          "\n\t-number of training reads\n\t-path to validation db"
+          "\n\t-max length of validation reads\n\nOptional:"
+          "\n\t-start position for validation\n\t-maximum number of reads for validation")
+_SHIPPED_HPARAMS = {
+    "RNN": dict(batch_size=256, optimizer_choice="Adam", learning_rate=0.001, layer_size=64, n_layers=3, keep_prob=0.8),
+    "ResNetRNN": dict(batch_size=256, optimizer_choice="RMSProp", learning_rate=0.001, layer_size=64, n_layers=3,
+                      keep_prob=0.8, layer_size_res=32, n_layers_res=2)}
+
+
+def _npz_files(directory):
+    return sorted(os.path.join(directory, f) for f in os.listdir(directory) if f.endswith(".npz"))
 
 
 def main(argv):
@@ -301,38 +395,25 @@ def main(argv):
     max_validation_length [validation_start [max_number]]``.  The training "database" argument is a directory of NPZ
     reads (the reference takes a ZODB file); hyper-parameters are a random draw as in the reference (:328) unless
     CATFISH_SHIPPED_HPARAMS=1 asks for the shipped network's (the reference's commented block :329-332)."""
-    if len(argv) < 6:
-        raise ValueError("The following arguments should be provided in this order:\n" +
-                         "\t-network type\n\t-path to training db" +
-                         "\n\t-number of training reads\n\t-path to validation db" +
-                         "\n\t-max length of validation reads\n\nOptional:" +
-                         "\n\t-start position for validation\n\t-maximum number of reads for validation")
-    network_type = argv[1]
-    db_dir_train = argv[2]
-    training_nr = int(argv[3])
-    db_dir_val = argv[4]
-    max_seq_length = int(argv[5])
-    validation_start = int(argv[6]) if len(argv) >= 7 else "random"
-    max_number = int(argv[7]) if len(argv) >= 8 else 856
-    if os.environ.get("CATFISH_SHIPPED_HPARAMS") != "1":
-        hpm_dict = generate_random_hyperparameters(network_type)
-    elif network_type == "RNN":
-        hpm_dict = {"batch_size": 256, "optimizer_choice": "Adam", "learning_rate": 0.001, "layer_size": 64,
-                    "n_layers": 3, "keep_prob": 0.8}
-    else:
-        hpm_dict = {"batch_size": 256, "optimizer_choice": "RMSProp", "learning_rate": 0.001, "layer_size": 64,
-                    "n_layers": 3, "keep_prob": 0.8, "layer_size_res": 32, "n_layers_res": 2}
-    network = build_model(network_type, save=True, **hpm_dict)
+    args = list(argv[1:])
+    if len(args) < 5:
+        raise ValueError(_USAGE)
+    kind, train_dir, val_dir = args[0], args[1], args[3]
+    n_train, stretch = int(args[2]), int(args[4])
+    start = int(args[5]) if len(args) > 5 else "random"
+    most = int(args[6]) if len(args) > 6 else 856
+    shipped = os.environ.get("CATFISH_SHIPPED_HPARAMS") == "1"
+    hparams = dict(_SHIPPED_HPARAMS.get(kind, _SHIPPED_HPARAMS["ResNetRNN"])) if shipped \
+        else generate_random_hyperparameters(kind)
+    network = build_model(kind, save=True, **hparams)
     network.initialize_network()
     print("Loading training database..")
-    db_train = example_db_from_npz(sorted(os.path.join(db_dir_train, f) for f in os.listdir(db_dir_train)
-                                          if f.endswith(".npz")))
+    db_train = example_db_from_npz(_npz_files(train_dir))
     print("Loading validation database..")
-    squiggles = sorted(os.path.join(db_dir_val, f) for f in os.listdir(db_dir_val) if f.endswith(".npz"))
-    t5 = datetime.datetime.now()
-    train_and_validate(network, db_train, training_nr, squiggles, max_seq_length, network.model_path,
-                       validation_start, max_number)
-    print("Trained and validated network in {}".format(datetime.datetime.now() - t5))
+    squiggles = _npz_files(val_dir)
+    began = datetime.datetime.now()
+    train_and_validate(network, db_train, n_train, squiggles, stretch, network.model_path, start, most)
+    print("Trained and validated network in {}".format(datetime.datetime.now() - began))
     print("Finished script at ", datetime.datetime.now())
 
 

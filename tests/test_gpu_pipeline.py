@@ -59,6 +59,38 @@ def test_test_network_counters(model, golden_read):
     assert model.fp == 0 and model.fn == 0
 
 
+def test_validation_round_is_one_packed_call_and_matches_the_oracle(model, ckpt_weights, tmp_path, monkeypatch):
+    """train_validate.validate on the HIP engine: all reads of a round through ONE cf_infer_host_logits call; its
+    report numbers against the same round scored read by read with the fp64 oracle's probabilities and logits."""
+    from catfish_amd import train_validate as tv
+    monkeypatch.chdir(tmp_path)
+    paths = []
+    for i, n in enumerate((1400, 735, 3000, 36, 2222, 700)):
+        raw, lab = tv.synthetic_labelled_read(n, seed=70 + i)
+        paths.append(str(tmp_path / ("sq%d.npz" % i)))
+        np.savez(paths[-1], raw=raw, base_labels=lab)
+    calls = []
+    real = model.engine.infer_host
+    monkeypatch.setattr(model.engine, "infer_host", lambda x, return_logits=False: (calls.append(np.shape(x)),
+                                                                                     real(x, return_logits))[1])
+    model.tp = model.fp = model.tn = model.fn = 0
+    acc, precision, recall = tv.validate(model, paths, 0, "round", "complete", 5)
+    assert len(calls) == 1 and calls[0] == (sum(-(-n // 35) for n in (1400, 735, 3000, 36, 2222)), 35, 1)
+    assert (model.tp, model.fp, model.tn, model.fn) == (0, 0, 0, 0)
+    # the same round from the oracle
+    signals, labels = tv.select_validation_stretches(paths, 35, 0, "complete", 5)
+    x, y, bounds, tails = tv.pack_validation_windows(signals, labels, 35)
+    p64, st = oracle.forward(x, ckpt_weights, np.float64, return_stages=True)
+    w_acc, w_loss, (tp, fp, tn, fn) = tv.score_validation_batch(p64.reshape(-1), st["logits"].reshape(-1), y, bounds, tails)
+    assert tp + fp + tn + fn == 1400 + 735 + 3000 + 36 + 2222
+    report = open("round.txt").read()
+    assert "Detected {} true positives, {} false positives, {} true negatives, {} false negatives".format(tp, fp, tn, fn) in report
+    assert "\tAccuracy: {:.2%}\n\tLoss: {:.4f}".format(float(np.sum(w_acc[:4].astype(float))) / 5,
+                                                      float(np.sum(w_loss[:4].astype(float))) / 5) in report
+    assert abs(acc - (tp + tn) / (tp + fp + tn + fn)) < 1e-12 and abs(precision - tp / max(tp + fp, 1)) < 1e-12
+    assert abs(recall - tp / max(tp + fn, 1)) < 1e-12
+
+
 def test_postprocess_kernel_matches_reference_semantics(model):
     torch = pytest.importorskip("torch")
     from catfish_amd import batching

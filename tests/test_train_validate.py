@@ -126,3 +126,93 @@ def test_save_info_writes_the_reference_report(tmp_path, monkeypatch, hp):
                                                   "learning_rate: 0.01\nlayer_size: 64\nn_layers: 2\nkeep_prob: 0.5\n")
     with pytest.raises(RuntimeError):
         ResNetRNN(**hp).save_info()                                           # no model directory claimed
+
+
+# ---------------------------------------------------------------- validate(): the reference's own report, byte for byte
+class _StubNetwork(object):
+    """The closed-form 'network' of tests/golden/validate_stub.py behind the surface ``validate`` uses."""
+    window, n_inputs, n_outputs, model_type = 35, 1, 1, "ResNet-RNN"
+
+    def __init__(self, a, b, counters):
+        self.a, self.b = a, b
+        self.tp, self.fp, self.tn, self.fn = counters
+        self.calls = []
+
+    def score_windows(self, windows):
+        from golden import validate_stub as stub
+        self.calls.append(np.asarray(windows).shape)
+        logits = stub.stub_logits(np.asarray(windows).reshape(-1), self.a, self.b)
+        return stub.stub_probs(logits), logits
+
+
+def _validate_golden():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "validate_golden.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.fixture()
+def golden_npz_reads(tmp_path):
+    paths = []
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "validate_golden_reads.npz")) as z:
+        for i in range(len(z.files) // 2):
+            paths.append(str(tmp_path / ("read_%02d.npz" % i)))
+            np.savez(paths[-1], raw=z["raw_%02d" % i], base_labels=z["labels_%02d" % i])
+    return paths
+
+
+@pytest.mark.parametrize("case", _validate_golden(), ids=lambda c: c["name"])
+def test_validate_reproduces_the_reference_report(case, golden_npz_reads, tmp_path, monkeypatch, capsys):
+    """tests/golden/make_validate_golden.py ran the reference's validate / padding / test_network / metrics functions
+    (lifted from its files) on these reads; the packed implementation must write the same bytes, print the same lines,
+    return the same numbers and leave the same counters -- incl. the max_number read that is counted but not averaged,
+    the p = 0.5 samples and zero tails that are called positive, and counters carried in from before."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    monkeypatch.chdir(tmp_path)
+    net = _StubNetwork(case["a"], case["b"], case["counters_before"])
+    if case["random_seed"] is not None:
+        random.seed(case["random_seed"])
+    capsys.readouterr()
+    got = tv.validate(net, golden_npz_reads, case["max_seq_length"], "some/dir/" + case["name"],
+                      case["validation_start"], case["max_number"])
+    assert capsys.readouterr().out == case["printed"]
+    assert open(case["name"] + ".txt").read() == case["report"]
+    assert [float(v) for v in got] == case["returned"]
+    assert [net.tp, net.fp, net.tn, net.fn] == case["counters_after"] == [0, 0, 0, 0]
+    assert len(net.calls) == 1                                                 # ONE packed launch per validation round
+
+
+def test_per_read_surface_agrees_with_the_packed_round(golden_npz_reads):
+    """RNN.test_network (one read per call, rnn_class.py:222-261) and the packed round count the same things."""
+    from catfish_amd.rnn_class import RNN
+
+    class PerRead(_StubNetwork):
+        test_network = RNN.test_network
+
+    a, b = 0.75, 0.375
+    net = PerRead(a, b, (0, 0, 0, 0))
+    signals, labels = tv.select_validation_stretches(golden_npz_reads, 35, 0, "complete", 856)
+    accs, losses = [], []
+    for s, l in zip(signals, labels):
+        x, pad = tv.padding(s)
+        y, _ = tv.padding(l)
+        acc, loss = net.test_network(x, y, "r", "f", pad)
+        accs.append(acc)
+        losses.append(loss)
+    x, y, bounds, tails = tv.pack_validation_windows(signals, labels, 35)
+    pk = _StubNetwork(a, b, (0, 0, 0, 0))
+    acc, loss, counts = tv.score_validation_batch(*pk.score_windows(x), y, bounds, tails)
+    assert counts == (net.tp, net.fp, net.tn, net.fn)
+    assert np.array_equal(acc, np.float32(accs)) and np.array_equal(loss, np.float32(losses))
+
+
+def test_validate_refuses_what_the_reference_cannot_run(golden_npz_reads, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    net = _StubNetwork(1.0, 0.0, (0, 0, 0, 0))
+    with pytest.raises(ZeroDivisionError):                                     # every read too short (:268 divides by 0)
+        tv.validate(net, golden_npz_reads, 35000, "m", 0, 856)
+    with pytest.raises(ValueError):
+        tv.validate(net, golden_npz_reads, 350, "m", "middle", 856)
+    assert not os.path.exists("m.txt") and net.calls == []
