@@ -14,8 +14,9 @@ ranks with no collective on the data path (weak scaling: every rank runs K steps
 ``value`` counts UN-PADDED signal samples (256 x 4096 per step and rank).  The line also carries
 informational objects that are never the value: ``other_precisions`` (bf16x3 / bf16 on the same
 workload, each with its own roofline), ``config4`` (BASELINE configs[3]: variable-length reads, packed,
-bf16), ``host_to_host_pipeline`` (PCIe-inclusive) and ``sharded_gather`` (BASELINE configs[2]'s path:
-reads sharded over the ranks, per-rank streaming pipeline, gloo host gather on rank 0).
+bf16), ``host_to_host_pipeline`` (PCIe-inclusive), ``sharded_gather`` (BASELINE configs[2]'s path:
+reads sharded over the ranks, per-rank streaming pipeline, gloo host gather on rank 0) and ``cli_end_to_end`` (the same
+shape through the product CLI: files in, merged chunk coordinates out as JSON, the merge tail on every rank).
 """
 from __future__ import annotations
 
@@ -258,6 +259,73 @@ def leg_sharded_gather(eng, weights, rank, world, dist, torch):
                     "span lists -> gloo gather_object on rank 0; PCIe, host span assembly and the gather included; never the headline value"}
 
 
+def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
+    """The product entry point on BASELINE configs[2]'s shape, files -> JSON: ``catfish_amd.cli.run_pipeline`` (the body of
+    catfish/catfish:23-94 up to the split step) over a directory of 12 500 x 4096-sample int16 reads per rank.  Every rank
+    loads, classifies AND merges / centres / complements its own files (catfish/catfish:50-82); rank 0 gathers the chunk
+    tables, formats and writes the two JSON documents.  Timed from the end of set-up (network loaded on every rank) to the
+    documents on disk; page cache warm (the files were just written)."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from catfish_amd import checkpoint, cli, sharding
+    n_total = SHARDED_READS_PER_RANK * world
+    box = [tempfile.mkdtemp(prefix="catfish_bench_") if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    root = box[0]
+    try:
+        if rank == 0:
+            os.makedirs(os.path.join(root, "reads"))
+            os.makedirs(os.path.join(root, "ResNetRNN", "checkpoints"))
+            with open(os.path.join(root, "ResNetRNN", "ResNetRNN.txt"), "w") as fh:
+                fh.write("MODEL TYPE: ResNet-RNN\n\nbatch_size: 256\noptimizer_choice: RMSProp\nlearning_rate: 0.001\n"
+                         "layer_size: 64\nn_layers: 3\nkeep_prob: 0.8\nlayer_size_res: 32\nn_layers_res: 2\n")
+            checkpoint.write_checkpoint(os.path.join(root, "ResNetRNN", "checkpoints", "ckpnt-30000"), weights)
+        if world > 1:
+            dist.barrier()
+        for i in range(rank, n_total, world):                 # every rank writes a share of the directory
+            np.save(os.path.join(root, "reads", "read_%06d.npy" % i), squiggle_dac(np.random.default_rng([1, i]), READ_LEN))
+        if world > 1:
+            dist.barrier()
+        timings = {}
+        sink = io.StringIO()
+        t0 = time.perf_counter()
+        failure = None
+        try:
+            with contextlib.redirect_stdout(sink):            # the pipeline prints the reference's progress lines
+                table = cli.run_pipeline(os.path.join(root, "reads"), os.path.join(root, "out"), chunk_size=1000,
+                                         network_path=os.path.join(root, "ResNetRNN"), device=local_rank, timings=timings)
+        except Exception as exc:                              # noqa: BLE001 -- raised below, after the barrier every rank reaches
+            failure = exc
+        total = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        if failure is not None:
+            raise failure
+        if rank != 0:
+            return None
+        dt = total - timings["setup_s"]
+        post = timings.get("assemble_s", 0.0) + timings.get("write_s", 0.0)
+        with open(os.path.join(root, "out", "TEMP", "hp_positions.json")) as fh:
+            hp = json.load(fh)
+        ok = len(table) == n_total and bool((table.lengths == READ_LEN).all()) and 0 < len(hp) <= n_total
+        return {"workload": "configs[2] through the CLI: %d files x %d samples (seed 1) over %d rank(s), %d per rank; chunk_size "
+                            "1000" % (n_total, READ_LEN, world, SHARDED_READS_PER_RANK),
+                "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "set_up_seconds": timings["setup_s"],
+                "rank0": {"infer_s": timings.get("infer_s"), "chunks_s": timings.get("chunks_s"),
+                          "assemble_s": timings.get("assemble_s"), "write_s": timings.get("write_s")},
+                "rank0_post_gather_frac": post / dt, "reads": n_total, "reads_with_hp": len(hp),
+                "hp_chunks": int(table.hp_bounds[-1]), "n_gpus": world, "results_ok": bool(ok),
+                "what": "int16 .npy files -> per-rank loader thread + ReadPipeline (cf_normalize, cf_infer, cf_postprocess, cf_spans) "
+                        "-> per-rank cf_chunks_from_spans (merge, center_hp, complement) -> gloo gather of chunk tables -> rank 0 "
+                        "cf_chunks_json + write; never the headline value"}
+    finally:
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -448,6 +516,15 @@ def main():
         if rank == 0:
             result["sharded_gather"] = sg
     eng.close()
+    if not args.no_sharded_leg and args.precision == "fp32":
+        try:
+            ce = leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch)
+        except Exception as exc:      # informational leg: never lose the headline line to it
+            ce = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if world > 1:
+                sys.stderr.write("bench.py: cli_end_to_end leg failed on rank %d: %s\n" % (rank, exc))
+        if rank == 0:
+            result["cli_end_to_end"] = ce
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

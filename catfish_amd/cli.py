@@ -4,7 +4,7 @@ Same options (``-i/--input-dir``, ``-s/--split-dir``, ``-c/--chunk-size`` defaul
 same pipeline: load the bundled ResNetRNN, predict homopolymer stretches per read, merge them
 into chunks of at least ``chunk_size`` samples, derive the non-HP complement, split the reads.
 All reads of the directory go through packed multi-read launches instead of one call per file, and
-the per-file loop (catfish/catfish:50-56) shards over the GPUs of the node: ``--gpus N`` (an MI355X
+the per-file loop with its merge tail (catfish/catfish:50-82) shards over the GPUs of the node: ``--gpus N`` (an MI355X
 addition) or ``python -m torch.distributed.run --nproc-per-node N -m catfish_amd.cli ...``.
 
 The FAST5 splitter (catfish/split_f5.py) is disk I/O around h5py and out of scope: when h5py
@@ -65,7 +65,9 @@ def nonhp_complement(merged_positions, len_read):
 
 
 def chunks_of_read(hp_positions, len_read, chunk_size=1000):
-    """catfish/catfish:57-82 for one read: (merged HP chunks or None, non-HP stretches)."""
+    """catfish/catfish:57-82 for one read: (merged HP chunks or None, non-HP stretches).  The per-read Python form of the
+    rules (pinned by tests/golden/postproc_golden.json, made from the reference's own functions); the pipeline runs them
+    for all reads of a rank at once in ``chunks.ChunkTable.from_spans``."""
     if hp_positions != []:
         merged_positions = merge_positions(hp_positions, len_read, chunk_size)
         return merged_positions, nonhp_complement(merged_positions, len_read)
@@ -73,69 +75,72 @@ def chunks_of_read(hp_positions, len_read, chunk_size=1000):
 
 
 def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN", network_type="ResNetRNN",
-                 checkpoint=30000, device=None, precision="fp32"):
+                 checkpoint=30000, device=None, precision="fp32", timings=None):
     """Body of the reference's ``main`` (catfish/catfish:23-94) up to the split step.
 
     Under ``torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the per-file loop of
-    catfish/catfish:50-56 is sharded: every rank loads and classifies its own files on its own MI355X
-    (``sharding.infer_files_sharded``) and rank 0, which gathers the spans over a gloo group, does the merging and
-    writes the output.  Returns ``(hp_dict, nonhp_dict)`` on rank 0 and ``(None, None)`` on the other ranks.
+    catfish/catfish:50-82 is sharded WITH its tail: every rank loads and classifies its own files on its own MI355X and
+    merges / centres / complements their spans (``sharding.chunk_files_sharded``); rank 0 receives the ranks' chunk
+    tables over a gloo group, concatenates them and writes the two JSON documents (formatted natively from the arrays).
+    Returns a ``chunks.ChunkTable`` with a ``names`` attribute on rank 0 (``.to_dicts(table.names)`` gives the reference's
+    ``hp_dict`` / ``nonhp_dict``) and None on the other ranks.  Files are taken in sorted order (the reference iterates in
+    ``os.listdir`` order, which is arbitrary), so N ranks write the same bytes as one.  ``timings`` (optional dict) receives
+    this rank's ``setup_s``, ``infer_s``, ``chunks_s`` and on rank 0 ``assemble_s`` / ``write_s``.
     """
+    import time
     from . import sharding
     rank, world, local_rank = sharding.dist_env()
     own_group = sharding.init_host_group()
+    timings = {} if timings is None else timings
+    finished = False
     try:
-        hp_dict = {}
-        nonhp_dict = {}
         temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
-        temp_dir_hp = "{}/HP".format(os.path.abspath(temp_dir))
-        temp_dir_nonhp = "{}/nonHP".format(os.path.abspath(temp_dir))
-        if rank == 0:
-            os.makedirs(temp_dir_hp)          # raises if they exist, like the reference (:37-38)
-            os.mkdir(temp_dir_nonhp)
-
         input_dir = os.path.abspath(input_dir)
-        input_files = sorted(os.listdir(input_dir)) if world > 1 else os.listdir(input_dir)   # one order on every rank
-
-        t1 = datetime.datetime.now()
         network_path = os.path.abspath(network_path)
-        # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
-        # tail instead of 8 % and the three layers go out as one dynamically scheduled launch (DESIGN.md, section 4).
-        max_windows = 131072 if len(input_files) > 400 * world else 32768
-        model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint,
-                                            device=_pick_device(local_rank) if device is None else device,
-                                            max_windows_per_pass=max_windows, precision=precision)
+        model = input_files = max_windows = None
+        t1 = datetime.datetime.now()
+        setup_error = None
+        try:
+            if rank == 0:
+                os.makedirs("{}/HP".format(temp_dir))      # raises if they exist, like the reference (:37-38)
+                os.mkdir("{}/nonHP".format(temp_dir))
+            input_files = sorted(os.listdir(input_dir))
+            # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
+            # tail instead of 8 % and the three layers go out as one dynamically scheduled launch (DESIGN.md, section 4).
+            max_windows = 131072 if len(input_files) > 400 * world else 32768
+            model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint,
+                                                device=_pick_device(local_rank) if device is None else device,
+                                                max_windows_per_pass=max_windows, precision=precision)
+        except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
+            setup_error = exc
+        sharding.agree_or_raise(setup_error, "set-up (output directories, network)")
+        timings["setup_s"] = (datetime.datetime.now() - t1).total_seconds()
         if rank == 0:
             print("Loaded model in {}".format(datetime.datetime.now() - t1))
             print("Checking for homopolymers in raw signal..")
         t2 = datetime.datetime.now()
-        results = sharding.infer_files_sharded(model, ["{}/{}".format(input_dir, f) for f in input_files],
-                                               max_samples_per_batch=max_windows * infer.WINDOW_SIZE,
-                                               gather_group=sharding.host_gather_group())
-        if rank != 0:
-            return None, None
-        from .batching import quiet_gc
-        with quiet_gc():                      # the merge loop creates as many small lists again
-            for fast5_file, (hp_positions, len_read) in zip(input_files, results):
-                merged_positions, nonhp = chunks_of_read(hp_positions, len_read, chunk_size)
-                if merged_positions is not None:
-                    hp_dict[fast5_file] = merged_positions
-                nonhp_dict[fast5_file] = nonhp
-        print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
-
-        print("Splitting reads...")
-        t3 = datetime.datetime.now()
-        with open(os.path.join(temp_dir, "hp_positions.json"), "w") as fh:
-            json.dump(hp_dict, fh)
-        with open(os.path.join(temp_dir, "nonhp_positions.json"), "w") as fh:
-            json.dump(nonhp_dict, fh)
-        print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
-            temp_dir, datetime.datetime.now() - t3))
-        return hp_dict, nonhp_dict
+        table = sharding.chunk_files_sharded(model, ["{}/{}".format(input_dir, f) for f in input_files], chunk_size,
+                                             max_samples_per_batch=max_windows * infer.WINDOW_SIZE,
+                                             gather_group=sharding.host_gather_group(), timings=timings)
+        if rank == 0:
+            print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
+            print("Splitting reads...")
+            t3 = time.perf_counter()
+            table.names = input_files
+            hp_text, nonhp_text = table.json_members(input_files)
+            for name, text in (("hp_positions.json", hp_text), ("nonhp_positions.json", nonhp_text)):
+                with open(os.path.join(temp_dir, name), "wb") as fh:
+                    fh.write(b"{" + text + b"}")
+            timings["write_s"] = time.perf_counter() - t3
+            print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
+                temp_dir, datetime.timedelta(seconds=timings["write_s"])))
+        finished = True
+        return table
     finally:
         if own_group:
             import torch.distributed as dist
-            dist.barrier()
+            if finished:                      # never a collective on the way out of a failure: the peers may not get there
+                dist.barrier()
             dist.destroy_process_group()
 
 
@@ -145,13 +150,22 @@ def _pick_device(local_rank):
     return int(os.environ["CATFISH_DEVICE"]) if "CATFISH_DEVICE" in os.environ else local_rank
 
 
+def free_port():
+    """A TCP port nobody listens on right now (for the launcher's rendezvous, so that two jobs on one node do not collide)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def launch_ranks(n_gpus, argv):
     """Start ``n_gpus`` ranks of this CLI under torch.distributed.run as a CHILD process (never an exec: nothing in
-    this process may have touched the GPU, and the child's exit code becomes ours)."""
+    this process may have touched the GPU, and the child's exit code becomes ours).  Rendezvous on 127.0.0.1 at
+    ``MASTER_PORT`` when the caller set one, else at a port that is free now."""
     import subprocess
     import sys
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
-           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT") or str(free_port()),
            "-m", "catfish_amd.cli"] + list(argv)
     return subprocess.call(cmd)
 

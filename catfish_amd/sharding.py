@@ -50,6 +50,24 @@ def shard_costs(costs, world_size):
     return [sorted(s) for s in shards]
 
 
+def shard_contiguous(costs, world_size):
+    """Contiguous blocks of item indices with near-equal cost: rank r gets ``[cut[r], cut[r+1])`` where the cuts sit at
+    the
+    item boundaries nearest to the multiples of total / world_size of the running cost (a block is off by at most one
+    item's cost).  Results gathered
+    in rank order are then already in item order, which lets rank 0 concatenate tables without re-ordering them."""
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    cost = np.asarray(costs, dtype=np.int64)
+    run = np.concatenate(([0], np.cumsum(cost)))
+    want = run[-1] * np.arange(1, world_size) / float(world_size)
+    hi = np.clip(np.searchsorted(run, want, side="left"), 1, len(cost)) if len(cost) else np.zeros(world_size - 1, np.int64)
+    cuts = np.where(run[hi] - want < want - run[hi - 1], hi, hi - 1) if len(cost) else hi      # the nearer of the two cuts
+    cuts = np.concatenate(([0], cuts, [len(cost)]))
+    cuts = np.maximum.accumulate(cuts)
+    return [list(range(int(cuts[r]), int(cuts[r + 1]))) for r in range(world_size)]
+
+
 def shard_reads(lengths, world_size):
     """LPT partition of reads by window count (the unit of device work)."""
     return shard_costs([windows_of(n) for n in lengths], world_size)
@@ -61,19 +79,43 @@ def dist_env():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_host_group():
+def init_host_group(timeout_s=None):
     """Initialise the process group of a sharded job when the launcher started more than one rank.
 
     gloo only: the data path has no collective, the group serves the final host gather (and barriers).
+    ``timeout_s`` (default ``CATFISH_DIST_TIMEOUT_S`` or 1800): how long a rank waits in a collective for the others --
+    it must cover the slowest rank's whole shard, because the fast ranks sit in the final gather meanwhile.
     Returns True when a group was created here (the caller then destroys it).
     """
+    import datetime
     import torch.distributed as dist
     _rank, world, _local = dist_env()
     if world <= 1 or (dist.is_available() and dist.is_initialized()):
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("CATFISH_DIST_TIMEOUT_S", "1800"))
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=float(timeout_s)))
     return True
+
+
+def agree_or_raise(error, stage, group=None):
+    """Every rank reports how its ``stage`` went (``error`` = the exception it caught, or None) and all of them learn the
+    outcome: a rank that failed re-raises its own exception, the others raise a RuntimeError naming it.  One small
+    all-gather; call it after any per-rank step that can fail BEFORE the data path (creating directories, loading the
+    network, opening the device), so that no rank walks into a later collective its peers will never reach."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if error is not None:
+            raise error
+        return
+    said = [None] * dist.get_world_size()
+    dist.all_gather_object(said, None if error is None else "%s: %s" % (type(error).__name__, error), group=group)
+    if error is not None:
+        raise error
+    bad = ["rank %d: %s" % (r, t) for r, t in enumerate(said) if t is not None]
+    if bad:
+        raise RuntimeError("%s failed on %s" % (stage, "; ".join(bad)))
 
 
 def host_gather_group():
@@ -129,12 +171,16 @@ class SpanTable(object):
         return [(pairs[bounds[r]:bounds[r + 1]], lens[r]) for r in range(n)]
 
 
-def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group=None):
+def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group=None, partition="lpt", assemble=None):
     """Shard ``len(costs)`` items by cost, run ``work_fn(list of my indices) -> list of results`` on this
     rank's shard, gather on rank 0.
 
     Returns the full result list in item order on rank 0 and None on the other ranks.  Without an
     initialised process group it simply runs everything locally.
+
+    ``partition``: "lpt" (greedy longest-processing-time deal, ``shard_costs``) or "contiguous" (``shard_contiguous``).
+    ``assemble``: when given, ``work_fn`` may return any picklable object with a length and rank 0 returns
+    ``assemble([(indices, result) of rank 0, of rank 1, ...])`` instead of a per-item list -- the way tables stay tables.
     """
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -143,15 +189,17 @@ def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group
     if world_size is None:
         world_size = dist.get_world_size() if distributed else 1
     n_items = len(costs)
-    shards = shard_costs(costs, world_size)
+    if partition not in ("lpt", "contiguous"):
+        raise ValueError("partition must be 'lpt' or 'contiguous'")
+    shards = shard_costs(costs, world_size) if partition == "lpt" else shard_contiguous(costs, world_size)
     mine = shards[rank]
     # A rank whose shard fails (unreadable file, device error) must still reach the gather, or the others would wait
     # for it until the process group times out: its error text travels in place of its results and every rank raises.
     failure = None
     local = []
     try:
-        local = work_fn(mine) if mine else []
-        if not isinstance(local, SpanTable):
+        local = work_fn(mine) if (mine or assemble is not None) else []
+        if assemble is None and not isinstance(local, SpanTable):
             local = list(local)
         if len(local) != len(mine):
             raise RuntimeError("work_fn returned %d results for %d items" % (len(local), len(mine)))
@@ -165,6 +213,8 @@ def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group
             out[i] = r
 
     if world_size == 1:
+        if assemble is not None:
+            return assemble([(mine, local)])
         out = [None] * n_items
         place(out, mine, local)
         return out
@@ -184,6 +234,8 @@ def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group
         raise RuntimeError("sharded run failed on " + verdict[0])
     if rank != 0:
         return None
+    if assemble is not None:
+        return assemble(gathered)
     out = [None] * n_items
     for idx, res in gathered:
         place(out, idx, res)
@@ -293,6 +345,40 @@ def _prefetched(gen, depth=3):
         yield item
 
 
+def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact):
+    """This rank's device work: the reads ``mine`` (indices into ``reads``) through the batch runner, batches cut at
+    ``max_samples_per_batch`` samples, files loaded a bounded number of batches ahead.  ``compact``: a ``SpanTable`` (arrays
+    end to end) instead of ``[(spans, length)]`` lists."""
+    runner = batch_runner if batch_runner is not None else EngineBatchRunner(model, max_samples_per_batch)
+
+    def batches():
+        if lengths is not None:
+            for idx in _batches_by_samples(mine, lengths, max_samples_per_batch):
+                yield [reads[i] if load_fn is None else load_fn(reads[i]) for i in idx]
+        else:                       # lengths unknown until loaded: cut a batch when the next read would not fit
+            cur, tot = [], 0
+            for i in mine:
+                r = load_fn(reads[i])
+                if cur and tot + len(r) > max_samples_per_batch:
+                    yield cur
+                    cur, tot = [], 0
+                cur.append(r)
+                tot += len(r)
+            if cur:
+                yield cur
+    source = _prefetched(batches(), depth=3) if load_fn is not None else batches()
+    if compact:
+        if isinstance(runner, EngineBatchRunner):
+            return SpanTable.concat(list(runner.run(source, compact=True)))
+        return SpanTable.concat([SpanTable.from_lists(res) for res in runner.run(source)])
+    # the per-read lists of batch k are built while the GPU runs batch k + 1 (0.3 ms per batch with the cyclic collector
+    # off, see batching.quiet_gc)
+    out = []
+    for res in runner.run(source):
+        out.extend(res)
+    return out
+
+
 def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_per_batch=None, batch_runner=None,
                         rank=None, world_size=None, gather_group=None, costs=None):
     """Homopolymer spans of many reads, sharded over the ranks of the job; rank 0 gets ``[(spans, length)]``
@@ -305,6 +391,9 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
     ``costs``      sharding weights (default: window counts from ``lengths``)
     ``batch_runner`` object with ``run(iterable of read batches) -> iterable of per-batch result lists``
                    (default: ``EngineBatchRunner(model)`` = the HIP engine of this rank)
+
+    This is the reference's RESULT TYPE (Python lists per read); a caller that goes on to merge the spans into chunks
+    wants ``chunk_files_sharded`` instead, where nothing leaves the flat tables.
     """
     n = len(reads)
     if lengths is None and load_fn is None:
@@ -319,40 +408,20 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
         return [] if (dist_env()[0] if rank is None else rank) == 0 else None
 
     def work(mine):
-        runner = batch_runner if batch_runner is not None else EngineBatchRunner(model, max_samples_per_batch)
-
-        def batches():
-            if lengths is not None:
-                for idx in _batches_by_samples(mine, lengths, max_samples_per_batch):
-                    yield [reads[i] if load_fn is None else load_fn(reads[i]) for i in idx]
-            else:                       # lengths unknown until loaded: cut a batch when the next read would not fit
-                cur, tot = [], 0
-                for i in mine:
-                    r = load_fn(reads[i])
-                    if cur and tot + len(r) > max_samples_per_batch:
-                        yield cur
-                        cur, tot = [], 0
-                    cur.append(r)
-                    tot += len(r)
-                if cur:
-                    yield cur
-        source = _prefetched(batches(), depth=3) if load_fn is not None else batches()
         import torch.distributed as dist
         n_ranks = world_size if world_size is not None else (
             dist.get_world_size() if dist.is_available() and dist.is_initialized() else dist_env()[1])
-        if isinstance(runner, EngineBatchRunner) and n_ranks > 1:
-            # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
-            return SpanTable.concat(list(runner.run(source, compact=True)))
-        # one rank: the per-read lists of batch k are built while the GPU runs batch k + 1 (0.3 ms per batch with the cyclic
-        # collector off, see batching.quiet_gc)
-        out = []
-        for res in runner.run(source):
-            out.extend(res)
-        return out
+        # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
+        compact = n_ranks > 1 and (batch_runner is None or isinstance(batch_runner, EngineBatchRunner))
+        return _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact)
 
     from .batching import quiet_gc
     with quiet_gc():
         return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group)
+
+
+def _file_costs(paths):
+    return [max(1, os.path.getsize(p)) if os.path.exists(p) else 1 for p in paths]
 
 
 def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=None, rank=None, world_size=None,
@@ -362,7 +431,46 @@ def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=N
     ``infer.load_dac`` -- one batch at a time, so host memory does not grow with the directory -- and rank 0
     receives ``[(spans, read length)]`` in the order of ``paths``."""
     from .infer import load_dac
-    costs = [max(1, os.path.getsize(p)) if os.path.exists(p) else 1 for p in paths]
-    return infer_reads_sharded(model, list(paths), lengths=None, load_fn=load_dac, costs=costs,
+    return infer_reads_sharded(model, list(paths), lengths=None, load_fn=load_dac, costs=_file_costs(paths),
                                max_samples_per_batch=max_samples_per_batch, batch_runner=batch_runner,
                                rank=rank, world_size=world_size, gather_group=gather_group)
+
+
+def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=None, batch_runner=None, rank=None,
+                        world_size=None, gather_group=None, timings=None):
+    """The WHOLE per-file loop body of the reference (catfish/catfish:55-82) sharded: a rank classifies its files and
+    also merges / centres / complements their spans (``chunks.ChunkTable``: one native call over the rank's span table),
+    so what travels to rank 0 is six small arrays per rank and what rank 0 does is concatenate them.  Files go to ranks
+    in contiguous blocks of near-equal size on disk (``shard_contiguous``), so the gathered tables are already in the order
+    of ``paths``.  -> ``ChunkTable`` over all files on rank 0, None elsewhere.  ``timings``: optional dict that receives this
+    rank's ``infer_s`` / ``chunks_s`` and, on rank 0, ``assemble_s``."""
+    import time
+    from .chunks import ChunkTable
+    from .infer import load_dac
+    paths = list(paths)
+    if max_samples_per_batch is None:
+        max_samples_per_batch = 32768 * WINDOW_SIZE
+    timings = {} if timings is None else timings
+
+    def work(mine):
+        t0 = time.perf_counter()
+        table = _spans_of_shard(model, paths, mine, None, load_dac, max_samples_per_batch, batch_runner, True) \
+            if mine else SpanTable([], [], [], [])
+        t1 = time.perf_counter()
+        out = ChunkTable.from_span_table(table, chunk_size)
+        timings["infer_s"], timings["chunks_s"] = t1 - t0, time.perf_counter() - t1
+        return out
+
+    def assemble(gathered):
+        t0 = time.perf_counter()
+        seen = [i for idx, _t in gathered for i in idx]
+        if seen != list(range(len(paths))):
+            raise RuntimeError("chunk_files_sharded: shards do not tile the file list")
+        out = ChunkTable.concat([t for _idx, t in gathered])
+        timings["assemble_s"] = time.perf_counter() - t0
+        return out
+
+    from .batching import quiet_gc
+    with quiet_gc():
+        return run_sharded_indexed(_file_costs(paths), work, rank=rank, world_size=world_size, gather_group=gather_group,
+                                   partition="contiguous", assemble=assemble)

@@ -170,6 +170,26 @@ int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_samples, int64_t 
 int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_offsets,
                  const int64_t* win_offsets, int64_t n_reads, float* x_out, void* stream);
 
+/* Pipeline tail on the HOST (no device work, no cf_model): what the reference's per-file loop does with the spans of a read
+ * (catfish/catfish:57-82 and center_hp, :121-135) for many reads held as flat tables.  Read r owns rows
+ * [bounds[r], bounds[r+1]) of a table; span_* = the [start - 11, end + 16] spans of infer_class_from_signal; lengths[r] =
+ * its second return value.  Output: hp_* = the merged, centred chunks (reads without spans get none and are absent from the
+ * reference's hp_dict), nonhp_* = the complement (reads without spans get the single row (0, length), which the reference
+ * stores as [([(0, len), len])], catfish:82).  Quirks kept: the merged list aliases the span lists, spans are edited in
+ * place, and `hp_positions[i - 1]` at i = 0 is the read's last span.
+ * Capacities (rows): hp >= n_spans + n_reads, nonhp >= n_spans + 2 n_reads always suffice. */
+int cf_chunks_from_spans(const int64_t* span_bounds, const int64_t* span_start, const int64_t* span_end,
+                         const int64_t* lengths, int64_t n_reads, int64_t chunk_size,
+                         int64_t* hp_bounds, int64_t* hp_start, int64_t* hp_end, int64_t hp_capacity,
+                         int64_t* nonhp_bounds, int64_t* nonhp_start, int64_t* nonhp_end, int64_t nonhp_capacity);
+/* The JSON members `"name": [[a, b], ...]` of such a table joined by ", " (json.dump's text between the braces) for the
+ * reads that own rows (whole_read == NULL: the reference's hp_dict) or for every read, "[]" when it owns none (whole_read
+ * given: its nonhp_dict, where whole_read[r] != 0 marks the reads to be written in the no-homopolymer form [[[a, b], b]]).
+ * keys = the names as JSON string literals back to back, key_bounds their byte offsets.  Returns bytes written (< 0: error;
+ * capacity of sum(key bytes) + 48 per row + 40 per read always suffices). */
+int64_t cf_chunks_json(const char* keys, const int64_t* key_bounds, int64_t n_reads, const int64_t* bounds,
+                       const int64_t* start, const int64_t* end, const uint8_t* whole_read, char* out, int64_t capacity);
+
 /* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
  * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,
  * on device buffers in the kernels' fragment layout [tile][t][mtile][lane][4] (tile = 16 windows; element

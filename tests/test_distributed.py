@@ -281,3 +281,120 @@ def test_eight_rank_gather_of_span_tables_with_empty_shards(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_eight_rank_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
     assert (tmp_path / "ok8_19").exists() and (tmp_path / "ok8_5").exists()
+
+
+# ------------------------------------------------------------------ the CLI with its tail on every rank (catfish/catfish:50-82)
+def _small_oracle_runner():
+    """An EngineBatchRunner whose device work is the CPU oracle on a tiny random network (16 units, one layer)."""
+    from catfish_amd import sharding
+    from oracle import catfish_oracle as oracle
+    w = oracle.random_weights(seed=3, layer_size=16, n_layers=1, layer_size_res=16, n_layers_res=1)
+    w["final_fully_connected/bias"] = np.array([0.4], np.float32)          # random weights: some samples over 0.5
+
+    def infer_read(r):
+        x = oracle.pad_and_window(oracle.normalize_raw_signal(np.asarray(r)))[0]
+        p = oracle.forward(x, w, np.float32, n_layers=1, n_layers_res=1)[:len(r)]
+        return oracle.hp_in_pred(oracle.correct_short(oracle.class_from_threshold(p))), len(r)
+
+    class Runner(sharding.EngineBatchRunner):
+        def __init__(self, model=None, max_samples_per_batch=None):
+            self.loaded = 0
+
+        def run(self, batches, compact=False):
+            for reads in batches:
+                self.loaded += len(reads)
+                res = [infer_read(r) for r in reads]
+                yield sharding.SpanTable.from_lists(res) if compact else res
+
+    return Runner, infer_read
+
+
+def _write_reads(directory, n_reads):
+    from oracle import catfish_oracle as oracle
+    os.makedirs(directory, exist_ok=True)
+    for i in range(n_reads):
+        np.save(os.path.join(directory, "read_%03d.npy" % i), oracle.synthetic_dac(1, 900 + 211 * (i % 7), seed=300 + i)[0])
+
+
+def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
+    sys.path.insert(0, ROOT)
+    import time
+    from catfish_amd import cli, sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), CATFISH_DIST_TIMEOUT_S="60")
+    Runner, _ = _small_oracle_runner()
+    sharding.EngineBatchRunner = Runner                                    # no GPU here: the oracle stands in for the engine
+
+    def load_network(*a, **k):
+        if break_setup == "network" and rank == world - 1:
+            raise ValueError("checkpoint is missing tensor 'conv1d/kernel'")
+        return object()
+
+    cli.neural_network.load_network = load_network
+    t0 = time.time()
+    try:
+        table = cli.run_pipeline(os.path.join(tmpdir, "reads"), os.path.join(tmpdir, out_name), chunk_size=300)
+        outcome = "returned %s" % (None if table is None else len(table))
+    except Exception as exc:                                               # noqa: BLE001 -- recorded for the parent
+        outcome = "%s %s" % (type(exc).__name__, exc)
+    open(os.path.join(tmpdir, "%s.rank%d" % (out_name, rank)), "w").write("%.1f %s" % (time.time() - t0, outcome))
+
+
+@pytest.mark.timeout(300)
+def test_eight_ranks_write_the_same_bytes_as_one(tmp_path):
+    """catfish -i -s over 8 gloo ranks vs 1: every rank classifies AND merges its own reads (native chunk tables), rank 0
+    concatenates and writes -- byte-identical documents, equal to the per-read Python rules on the per-read results."""
+    import json
+    import torch.multiprocessing as mp
+    from catfish_amd import cli
+    n_reads = 21
+    _write_reads(str(tmp_path / "reads"), n_reads)
+    mp.spawn(_pipeline_worker, args=(8, _free_port(), str(tmp_path), n_reads, "out8", None), nprocs=8, join=True)
+    mp.spawn(_pipeline_worker, args=(1, _free_port(), str(tmp_path), n_reads, "out1", None), nprocs=1, join=True)
+    assert (tmp_path / "out8.rank0").read_text().endswith("returned %d" % n_reads)
+    assert all((tmp_path / ("out8.rank%d" % r)).read_text().endswith("returned None") for r in range(1, 8))
+    docs = {}
+    for out in ("out8", "out1"):
+        docs[out] = [(tmp_path / out / "TEMP" / f).read_bytes() for f in ("hp_positions.json", "nonhp_positions.json")]
+    assert docs["out8"] == docs["out1"]
+    hp, nonhp = (json.loads(d) for d in docs["out8"])
+    _, infer_read = _small_oracle_runner()
+    assert len(nonhp) == n_reads and 0 < len(hp) <= n_reads
+    for name in sorted(os.listdir(tmp_path / "reads")):
+        spans, length = infer_read(np.load(tmp_path / "reads" / name))
+        merged, non = cli.chunks_of_read([list(s) for s in spans], length, 300)
+        assert hp.get(name) == merged and nonhp[name] == json.loads(json.dumps(non))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("what", ["directories", "network"])
+def test_a_rank_that_fails_during_set_up_fails_the_job_at_once(tmp_path, what):
+    """a failure BEFORE the data path (rank 0: the split directory exists, catfish/catfish:37-38; any rank:
+    the network does not load) used to leave the failing rank in a barrier and the others in the gather until the group
+    timed out.  Now the ranks compare notes after set-up: the failing one raises its own error, the others name it."""
+    import torch.multiprocessing as mp
+    _write_reads(str(tmp_path / "reads"), 4)
+    if what == "directories":
+        os.makedirs(tmp_path / "out" / "TEMP" / "HP")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 4, "out", what), nprocs=2, join=True)
+    r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
+    assert float(r0[0]) < 30 and float(r1[0]) < 30
+    if what == "directories":
+        assert r0[1].startswith("FileExistsError") and r1[1].startswith("RuntimeError") and "rank 0: FileExistsError" in r1[1]
+    else:
+        assert r1[1].startswith("ValueError") and r0[1].startswith("RuntimeError") and "rank 1: ValueError" in r0[1]
+
+
+def test_contiguous_shards_tile_in_order_and_balance():
+    sys.path.insert(0, ROOT)
+    from catfish_amd import sharding
+    rng = np.random.default_rng(9)
+    costs = rng.integers(1, 500, size=300)
+    for world in (1, 2, 3, 8):
+        shards = sharding.shard_contiguous(costs, world)
+        assert sum(shards, []) == list(range(300))                          # blocks in order: gathered tables need no re-ordering
+        loads = [int(costs[s].sum()) for s in shards]
+        assert max(loads) - min(loads) <= 2 * int(costs.max())
+    assert sharding.shard_contiguous([1, 1], 4) == [[], [0], [], [1]] and sharding.shard_contiguous([], 3) == [[], [], []]
+    with pytest.raises(ValueError):
+        sharding.shard_contiguous([1], 0)

@@ -68,6 +68,78 @@ def test_cli_tail_matches_reference(golden):
         assert cli.nonhp_complement(merged, c["len_read"]) == c["nonhp"]
 
 
+def test_native_chunk_tables_follow_the_reference_rules(golden):
+    """chunks.ChunkTable.from_spans (cf_chunks_from_spans: host code of the C-ABI library, no GPU needed) = the reference's
+    merge / center_hp / complement loop (catfish/catfish:57-82,121-135) for every read of a table: against the goldens made
+    from the reference's own functions, and against the per-read Python rules on random reads -- incl. reads whose FIRST span
+    is longer than a chunk (the merged list then holds the same list object twice and `hp_positions[i - 1]` is the LAST span),
+    reads without spans (the odd `[([(0, len), len])]` entry) and reads that their chunks cover completely (`[]`)."""
+    import copy
+    import json
+    from catfish_amd import chunks
+    # 1. the reference-executed goldens, one table per chunk size
+    for size in sorted({c["chunk_size"] for c in golden["merge"]}):
+        cases = [c for c in golden["merge"] if c["chunk_size"] == size]
+        bounds = np.concatenate(([0], np.cumsum([len(c["spans"]) for c in cases])))
+        flat = np.array([sp for c in cases for sp in c["spans"]], dtype=np.int64).reshape(-1, 2)
+        tab = chunks.ChunkTable.from_spans(bounds, flat[:, 0], flat[:, 1], [c["len_read"] for c in cases], size)
+        hp, non = tab.to_dicts(list(range(len(cases))))
+        for i, c in enumerate(cases):
+            assert hp[i] == c["merged"] and non[i] == c["nonhp"]
+    # 2. random reads against the Python rules, through the JSON text
+    rng = np.random.default_rng(0)
+    reads = []
+    for _ in range(1500):
+        length = int(rng.integers(20, 9000))
+        spans, pos = [], int(rng.integers(-11, 200))
+        while rng.random() > 0.1:
+            n = int(rng.choice([15, 20, 40, 100, 600, 1200, 2500])) + 27
+            if pos + n > length + 16:
+                break
+            spans.append([pos, pos + n])
+            pos += n + int(rng.integers(1, 900))
+        reads.append((spans, length))
+    assert sum(1 for sp, _n in reads if sp and sp[0][1] - sp[0][0] >= 1000) > 50 and sum(1 for sp, _n in reads if not sp) > 50
+    names = ["read_%d.fast5" % i for i in range(len(reads))]
+    names[5] = 'we"ird\\name\u00e9.fast5'
+    want_hp, want_non = {}, {}
+    for name, (spans, length) in zip(names, reads):
+        merged, non = cli.chunks_of_read(copy.deepcopy(spans), length, 1000)
+        if merged is not None:
+            want_hp[name] = merged
+        want_non[name] = non
+    assert any(v == [] for v in want_non.values())
+    bounds = np.concatenate(([0], np.cumsum([len(sp) for sp, _n in reads])))
+    flat = np.array([p for sp, _n in reads for p in sp], dtype=np.int64).reshape(-1, 2)
+    tab = chunks.ChunkTable.from_spans(bounds, flat[:, 0], flat[:, 1], [n for _sp, n in reads], 1000)
+    for plain in (False, True):                                # escaped keys, then the no-escaping fast path
+        keys = ["r%d" % i for i in range(len(names))] if plain else names
+        hp_text, non_text = tab.json_members(keys)
+        ren = dict(zip(names, keys))
+        assert b"{" + hp_text + b"}" == json.dumps({ren[k]: v for k, v in want_hp.items()}).encode()
+        assert b"{" + non_text + b"}" == json.dumps({ren[k]: v for k, v in want_non.items()}).encode()
+    got_hp, got_non = tab.to_dicts(names)
+    assert got_hp == want_hp and json.dumps(got_non) == json.dumps(want_non)
+    # 3. tables concatenate and re-order like lists of reads
+    cut = [0, 1, 700, 700, 1500]
+    parts = [chunks.ChunkTable.from_spans(bounds[a:b + 1], flat[:, 0], flat[:, 1], [n for _sp, n in reads[a:b]], 1000)
+             for a, b in zip(cut[:-1], cut[1:])]
+    assert chunks.ChunkTable.concat(parts).json_members(names) == tab.json_members(names)
+    order = rng.permutation(len(reads))
+    assert tab.take(order).json_members([names[i] for i in order]) == \
+        chunks.ChunkTable.from_spans(*_reordered(bounds, flat, reads, order), 1000).json_members([names[i] for i in order])
+    empty = chunks.ChunkTable.concat([])
+    assert len(empty) == 0 and empty.json_members([]) == (b"", b"") and empty.to_dicts([]) == ({}, {})
+    with pytest.raises(ValueError):
+        chunks.ChunkTable.from_spans([0, 1], [5], [9], [100, 200], 1000)
+
+
+def _reordered(bounds, flat, reads, order):
+    rows = np.concatenate([np.arange(bounds[i], bounds[i + 1]) for i in order]).astype(np.int64)
+    nb = np.concatenate(([0], np.cumsum([bounds[i + 1] - bounds[i] for i in order])))
+    return nb, flat[rows, 0], flat[rows, 1], [reads[i][1] for i in order]
+
+
 def test_cli_options_match_reference():
     main = cli._build_click_main()
     opts = {o.name: o for o in main.params}
