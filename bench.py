@@ -13,8 +13,8 @@ ranks with no collective on the data path (weak scaling: every rank runs K steps
 
 ``value`` counts UN-PADDED signal samples (256 x 4096 per step and rank).  The line also carries
 informational objects that are never the value: ``other_precisions`` (bf16x3 / bf16 on the same
-workload, each with its own roofline), ``config4`` (BASELINE configs[3]: variable-length reads, packed,
-bf16), ``host_to_host_pipeline`` (PCIe-inclusive), ``sharded_gather`` (BASELINE configs[2]'s path:
+workload, each with its own roofline), ``config4`` (BASELINE configs[3]: 10 000 variable-length reads, packed,
+bf16), ``latency`` (118- and 256-window calls), ``config5`` (BASELINE configs[4]: the training step), ``host_to_host_pipeline`` (PCIe-inclusive), ``sharded_gather`` (BASELINE configs[2]'s path:
 reads sharded over the ranks, per-rank streaming pipeline, gloo host gather on rank 0) and ``cli_end_to_end`` (the same
 shape through the product CLI: files in, merged chunk coordinates out as JSON, the merge tail on every rank).
 """
@@ -38,9 +38,12 @@ FLOP_PER_SAMPLE = 389504            # SURVEY.md 8d / BASELINE.md 2 (2 x 194 752 
 FLOP_PER_SAMPLE_GRU128 = 2 * 2 * (128 + 64) * 192   # one CIN=128 biGRU layer: 2 dirs x 2 FLOP x 192x192 MAC
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
-PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md, HBM3E peak (about 6.3 TB/s is achievable on a copy)
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md, HBM3E peak
+ACHIEVABLE_HBM_GBS = 6300.0         # what a device-to-device copy sustains on this chip (same guide)
+MID_LAYER_BYTES_PER_SAMPLE = {"fp32": 128 * 4 * 2, "bf16": 128 * 2 * 2}   # a CIN = 128 biGRU layer: input slab + output slab
 SHARDED_READS_PER_RANK = 12500      # BASELINE configs[2]: 100 000 reads over 8 GPUs
-CONFIG4_READS = 2048                # BASELINE configs[3] names 10 000 reads; the informational leg times a 2048-read sample
+CONFIG4_READS = 10000               # BASELINE configs[3]
+CONFIG4_PARITY_READS = 32           # reads of it checked against the fp32 oracle (shortest, longest, 30 spread over the rest)
 
 
 def squiggle_dac(rng, length):
@@ -115,14 +118,34 @@ def mid_roofline(kern, precision, samples_per_launch, traffic=None, traffic_sour
     peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     kname = {"fp32": "gru_layer_kernel<128,false>", "bf16x3": "gru_layer_bf16_kernel<128,false,2>",
              "bf16": "gru_bf16_pipe_kernel<128,false>"}[precision]
+    launch_s = ms / n * 1e-3
     roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": ms / n,
             "flop_per_launch": FLOP_PER_SAMPLE_GRU128 * samples_per_launch}
-    if traffic:
-        # the other roof, for the reader: measured fabric bytes of this kernel over its live launch time against 8 TB/s
-        # (the bf16 mid layer moves 768 B per sample and sits nearer this roof than the matrix one)
-        roof["hbm_view"] = {"achieved": traffic / (ms / n * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": traffic / (ms / n * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    return nearer_roof(roof, precision, samples_per_launch, launch_s)
+
+
+def nearer_roof(roof, precision, samples, seconds):
+    """Report the dominant kernel against the roof it sits nearer to.  Its own algorithmic bytes are its input and output
+    slabs (128 features per sample in, 128 out, 4 B each in fp32 / bf16x3 and 2 B in bf16); the matrix
+    view is kept as ``mfma_view`` when HBM is the binding roof, and the measured fabric traffic (when a stored PMC record
+    exists) as ``traffic`` plus ``traffic_rate_frac`` = traffic / time / 8 TB/s (about 6.3 TB/s is achievable on a copy)."""
+    bytes_per_sample = MID_LAYER_BYTES_PER_SAMPLE["bf16" if precision == "bf16" else "fp32"]
+    hbm = bytes_per_sample * samples / seconds / 1e9
+    hbm_view = {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
+                "algorithmic_bytes": bytes_per_sample * samples, "achievable_peak": ACHIEVABLE_HBM_GBS}
+    if roof.get("traffic"):
+        hbm_view["traffic_rate"] = roof["traffic"] / seconds / 1e9
+        hbm_view["traffic_rate_frac"] = hbm_view["traffic_rate"] / PEAK_HBM_GBS
+    # bf16: the matrix roof is 16x further away than in fp32 while the slabs only halve -- whichever fraction is larger binds;
+    # the measured traffic (1.5x the algorithmic bytes: each direction reads the whole input slab) decides a near tie
+    nearest = max(hbm_view["frac"], hbm_view.get("traffic_rate_frac", 0.0))
+    if nearest > roof["frac"]:
+        mfma_view = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
+        roof.update(bound="hbm", achieved=hbm, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm / PEAK_HBM_GBS, mfma_view=mfma_view,
+                    hbm_detail=hbm_view)
+    else:
+        roof["hbm_view"] = hbm_view
     return roof
 
 
@@ -185,8 +208,9 @@ def leg_config4(weights, local_rank, torch):
     dt = (time.perf_counter() - t0) / rep
     kern = eng.profile_read()
     eng.profile_enable(False)
-    # parity on four reads (shortest, longest, two others) against the fp32 oracle, as SURVEY 8d asks for this config
-    idx = [int(np.argmin(lens)), int(np.argmax(lens)), 0, 1]
+    # parity on 32 reads (shortest, longest, 30 spread over the rest) against the fp32 oracle, as SURVEY 8d asks for this config
+    idx = sorted({int(np.argmin(lens)), int(np.argmax(lens))} |
+                 {int(i) for i in np.linspace(0, CONFIG4_READS - 1, CONFIG4_PARITY_READS - 2).astype(int)})
     _, probs = batching.infer_reads_dac(eng, [dacs[i] for i in idx], max_windows=max_windows, return_probs=True)
     n_match = n_tot = 0
     maxdp = 0.0
@@ -209,13 +233,78 @@ def leg_config4(weights, local_rank, torch):
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                 "traffic": None, "kernel": "gru_bf16_pipe_kernel<128,false>", "launches_per_repetition": n // rep,
                 "ms_per_repetition": ms / rep}
+        roof = nearer_roof(roof, "bf16", total, mid_s)
     return {"workload": "configs[3]: %d reads, lengths LogUniform[512,16384] (seed 2), DAC squiggles, length-bucketed packed "
                         "launches of <= %d windows, bf16 biGRU arithmetic, device-resident" % (CONFIG4_READS, max_windows),
             "value": value, "unit": "samples/s", "dtype": "bf16 (f32 accumulate)", "reads": CONFIG4_READS, "buckets": len(packed),
             "total_samples": total, "padding_overhead": windows * WINDOW / total - 1.0, "ms_per_pass": dt * 1e3,
             "whole_pass_frac_of_bf16_peak": value * FLOP_PER_SAMPLE / 1e12 / PEAK_BF16_MFMA_TFLOPS,
             "roofline": roof, "kernels_ms_per_pass": {k: v[0] / rep for k, v in kern.items()},
-            "label_match_vs_fp32_oracle": n_match / n_tot, "max_abs_dp_vs_fp32_oracle": maxdp, "parity_sample": "%d samples of 4 reads" % n_tot}
+            "label_match_vs_fp32_oracle": n_match / n_tot, "max_abs_dp_vs_fp32_oracle": maxdp, "parity_sample": "%d samples of %d reads" % (n_tot, len(idx))}
+
+
+def leg_config5(weights, local_rank, torch):
+    """BASELINE configs[4] (SURVEY 8d "config 5"): the training step of RNN.train_network (rnn_class.py:201-210) --
+    forward, loss, backward, Adam(1e-3), keep_prob 0.8 -- on balanced batches of uniform-label windows
+    (ExampleDb.get_training_set's shape, networks/trainingDB/ExampleDb.py:50-83), the whole step on HIP kernels through the
+    C ABI (catfish_amd/native_step.py).  ms/step and windows/s at 256 (the reference's batch) and 4096 windows, and the
+    10-step loss trajectory with dropout off next to the torch-CPU trainer of the same graph."""
+    from catfish_amd.training import Trainer
+    out = {"what": "forward + sigmoid cross-entropy + backward + TF-rule Adam(lr 1e-3), dropout keep_prob 0.8 on the biGRU outputs; "
+                   "synthetic config-2 windows, labels uniform per window, half positive; never the headline value"}
+    pool = make_reads(40, seed=5).reshape(-1, WINDOW)
+    rng = np.random.default_rng(0)
+    dev = "cuda:%d" % local_rank
+    for batch in (256, 4096):
+        x = pool[rng.permutation(len(pool))[:batch]]
+        y = np.repeat((np.arange(batch) % 2)[:, None], WINDOW, axis=1).astype(np.float32)
+        tr = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=0.8, device=dev, seed=0)
+        for _ in range(5):
+            tr.train_step(x, y)
+        torch.cuda.synchronize()
+        n = 30
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.train_step(x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out["batch_%d" % batch] = {"ms_per_step": dt * 1e3, "windows_per_s": batch / dt, "native_step": bool(tr.step_impl is not None)}
+        if batch == 256:
+            gpu = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)
+            cpu = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
+            lg = [float(gpu.train_step(x, y)) for _ in range(10)]
+            lc = [float(cpu.train_step(x, y)) for _ in range(10)]
+            out["loss_10_steps_dropout_off"] = {"device": lg, "torch_cpu": lc,
+                                                "max_abs_diff": float(np.max(np.abs(np.array(lg) - np.array(lc))))}
+    return out
+
+
+def leg_latency(eng, torch, local_rank):
+    """Small calls, fp32: one 4096-sample read (118 windows -- the reference's per-read ``model.infer``, infer.py:44) and a
+    256-window micro-batch, device-resident in -> out with a synchronise per call, and the 118-window call with
+    numpy in / numpy out (cf_infer_host: H2D and D2H inside)."""
+    dev = torch.device("cuda", local_rank)
+    out = {"what": "ms per call, fp32, one call in flight (synchronised after every call); never the headline value"}
+    for n in (118, 256):
+        x = torch.randn(n, WINDOW, device=dev)
+        y = torch.empty(n * WINDOW, device=dev)
+        for _ in range(10):
+            eng.infer_device(x, out=y)
+        torch.cuda.synchronize()
+        reps = 100
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.infer_device(x, out=y)
+            torch.cuda.synchronize()
+        out["%d_windows_ms" % n] = (time.perf_counter() - t0) / reps * 1e3
+    xh = np.random.default_rng(0).normal(size=(118, WINDOW, 1))
+    for _ in range(5):
+        eng.infer_host(xh)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.infer_host(xh)
+    out["118_windows_host_numpy_in_out_ms"] = (time.perf_counter() - t0) / 50 * 1e3
+    return out
 
 
 def leg_sharded_gather(eng, weights, rank, world, dist, torch):
@@ -490,6 +579,12 @@ def main():
             e2.close()
         result["other_precisions"] = extra
         result["config4"] = leg_config4(weights, local_rank, torch)
+        for name, leg in (("latency", lambda: leg_latency(eng, torch, local_rank)),
+                          ("config5", lambda: leg_config5(weights, local_rank, torch))):
+            try:
+                result[name] = leg()
+            except Exception as exc:      # informational legs: never lose the headline line to them
+                result[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         # informational: host-to-host rate of the streaming pipeline (pinned int16 DAC in, spans out, PCIe inclusive)
         from catfish_amd.pipeline import ReadPipeline
         _, dacs = make_reads(READS_PER_STEP, seed=77, return_dac=True)

@@ -12,7 +12,27 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CATFISH_HIP_LIB") or os.path.join(_HERE, "csrc", "libcatfish_hip.so")
+DEFAULT_LIB_PATH = os.path.join(_HERE, "csrc", "libcatfish_hip.so")
+
+
+def debug_knobs_on():
+    """``CATFISH_DEBUG_KNOBS=1``: the ONE switch behind which the A/B knobs of tools/ and tests live -- the library's
+    ``CATFISH_*`` kernel-selection variables (csrc/catfish_hip.hip ``cf_knob``) and ``CATFISH_HIP_LIB`` here.  Without it a
+    stray environment variable changes nothing; with it every knob that takes effect is named on stderr."""
+    return os.environ.get("CATFISH_DEBUG_KNOBS", "0") not in ("", "0")
+
+
+def _lib_path():
+    override = os.environ.get("CATFISH_HIP_LIB")
+    if override and debug_knobs_on():
+        import sys
+        sys.stderr.write("catfish_amd: debug knob CATFISH_HIP_LIB=%s is active (NOT the in-tree library)\n" % override)
+        return override
+    return DEFAULT_LIB_PATH
+
+
+LIB_PATH = DEFAULT_LIB_PATH
+CF_ABI_VERSION = 3            # include/catfish_hip.h
 
 CF_OK = 0
 CF_ERR_INVALID = -1
@@ -70,6 +90,7 @@ SYMBOLS = {
     "cf_infer_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_infer_host_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cf_check_error": (C.c_int, [C.c_void_p]),
+    "cf_clear_error": (C.c_int, [C.c_void_p]),
     "cf_launch_regimes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "cf_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -115,6 +136,7 @@ SYMBOLS = {
     "cf_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "cf_last_error": (C.c_char_p, []),
     "cf_version": (C.c_char_p, []),
+    "cf_abi_version": (C.c_int, []),
 }
 
 
@@ -138,19 +160,28 @@ def _preload_torch_hip_runtime():
 
 def lib():
     """Load (once) and return the C-ABI library; raise loudly when it is absent."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = _lib_path()
+        if not os.path.exists(path):
             raise NativeLibraryMissing(
                 "%s not found: the HIP extension has not been built. Run "
-                "`python -m catfish_amd.build` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+                "`python -m catfish_amd.build` (needs hipcc). There is no CPU fallback." % path)
         _preload_torch_hip_runtime()
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
+        try:
+            abi = getattr(handle, "cf_abi_version")
+        except AttributeError:
+            abi = None
+        built = int(abi()) if abi is not None else None
+        if built != CF_ABI_VERSION:
+            raise NativeLibraryMissing("%s was built for ABI %s, this binding needs %d: rebuild it "
+                                       "(`python -m catfish_amd.build --force`)" % (path, built, CF_ABI_VERSION))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
+        _lib, LIB_PATH = handle, path
     return _lib
 
 

@@ -26,6 +26,8 @@
 #include <vector>
 #include <string>
 #include <cmath>
+#include <mutex>
+#include <set>
 
 #include "../../include/catfish_hip.h"
 
@@ -923,6 +925,23 @@ __global__ __launch_bounds__(256) void normalize_kernel(const int16_t* __restric
 // ==========================================================================================
 #include "generic.hpp"
 
+// A/B and test knobs: environment variables (CATFISH_GENERIC, CATFISH_WAVES, CATFISH_BF16_PIPE, ... -- tools/README.md lists
+// them) that change WHICH kernels a call uses.  They are for tools/ and tests and are honoured only while
+// CATFISH_DEBUG_KNOBS=1 is set as well; every knob that takes effect is named once on stderr, so a stray variable can
+// neither change results nor do so silently.
+static const char* cf_knob(const char* name) {
+    const char* on = getenv("CATFISH_DEBUG_KNOBS");
+    if (!on || atoi(on) == 0) return nullptr;
+    const char* v = getenv(name);
+    if (v) {
+        static std::mutex mu;
+        static std::set<std::string> seen;
+        std::lock_guard<std::mutex> lock(mu);
+        if (seen.insert(std::string(name) + "=" + v).second) fprintf(stderr, "catfish_hip: debug knob %s=%s is active\n", name, v);
+    }
+    return v;
+}
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string& msg) {
@@ -1253,14 +1272,14 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
             // small calls: room for one layer's hoisted x projection (CATFISH_HOIST_TILES: A/B knob for tools/)
             // measured crossover (tools/bench_latency.py with CATFISH_HOIST_TILES): hoisting pays up to ~48 tiles = 768 windows
             int xpt = (int)std::min<int64_t>(m->cap_tiles, std::max(1, 3 * m->n_cu / 16));
-            if (getenv("CATFISH_HOIST_TILES")) xpt = std::max(1, std::min(atoi(getenv("CATFISH_HOIST_TILES")), (int)m->cap_tiles));
+            if (cf_knob("CATFISH_HOIST_TILES")) xpt = std::max(1, std::min(atoi(cf_knob("CATFISH_HOIST_TILES")), (int)m->cap_tiles));
             e = hipMalloc((void**)&m->d_xp, (size_t)xpt * CF_T * 2 * 12 * 64 * sizeof(f32x4));
             if (e == hipSuccess) m->xp_tiles = xpt;
         }
         if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_err, sizeof(unsigned), hipHostMallocMapped);
         if (e == hipSuccess) { *m->h_err = 0u; e = hipHostGetDevicePointer((void**)&m->d_err, m->h_err, 0); }
         m->fuse = (m->np == 0 && hp->n_layers <= 3 && hp->fuse_layers >= 0) ? (hp->fuse_layers > 0 ? 1 : 2) : 0;
-        if (getenv("CATFISH_FUSE") && m->fuse) m->fuse = atoi(getenv("CATFISH_FUSE")) != 0 ? 1 : 0;   // A/B knob for tools/
+        if (cf_knob("CATFISH_FUSE") && m->fuse) m->fuse = atoi(cf_knob("CATFISH_FUSE")) != 0 ? 1 : 0;   // A/B knob for tools/
         if (e != hipSuccess) rc = fail(CF_ERR_NOMEM, std::string("workspace allocation: ") + hipGetErrorString(e));
         m->ws_bytes = (int64_t)n_slots * (int64_t)(2 * a_bytes + 2 * y_bytes + p_bytes);
     }
@@ -1342,7 +1361,7 @@ static int pick_waves(int n_tile_tasks, int n_cu) {
 
 // latency mode: up to two rounds of one (tile, direction) per CU (0.35 units each) beat one wave per tile (1 unit)
 static bool use_coop(const cf_model* m, int n_tiles) {
-    static const int coop_env = getenv("CATFISH_COOP") ? atoi(getenv("CATFISH_COOP")) : -1;      // A/B knob for tools/
+    static const int coop_env = cf_knob("CATFISH_COOP") ? atoi(cf_knob("CATFISH_COOP")) : -1;      // A/B knob for tools/
     const bool coop = coop_env >= 0 ? coop_env != 0 : n_tiles <= m->n_cu;
     return coop && !(CF_ABLATE & 4) && n_tiles <= m->n_cu;      // (the raw dense-partial buffer is sized for n_cu tiles)
 }
@@ -1365,7 +1384,7 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
         HIP_TRY(hipGetLastError());
         return prof_end(m, s, pi);
     }
-    static const int waves_env = getenv("CATFISH_WAVES") ? atoi(getenv("CATFISH_WAVES")) : 0;     // A/B knob for tools/
+    static const int waves_env = cf_knob("CATFISH_WAVES") ? atoi(cf_knob("CATFISH_WAVES")) : 0;     // A/B knob for tools/
     // (12 waves = 3 per SIMD measured +0.3 % on the Cin = 128 layers and costs the Cin = 32 layer its second workgroup per CU)
     const int waves = waves_env > 0 ? std::min(waves_env, 8) : ((CF_ABLATE & 4) ? 4 : pick_waves(2 * n_tiles, m->n_cu));
     const int groups = (n_tiles + waves - 1) / waves;             // one workgroup pass = one tile per wave
@@ -1384,8 +1403,8 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
 
 template <int CIN, bool LAST, int NP>
 static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float* Y, float* P, int n_tiles32, hipStream_t s, int slot) {
-    static const int waves_env = getenv("CATFISH_BF16_WAVES") ? atoi(getenv("CATFISH_BF16_WAVES")) : 0;     // A/B knobs for tools/
-    static const int wgs_env = getenv("CATFISH_BF16_WGS") ? atoi(getenv("CATFISH_BF16_WGS")) : 0;
+    static const int waves_env = cf_knob("CATFISH_BF16_WAVES") ? atoi(cf_knob("CATFISH_BF16_WAVES")) : 0;     // A/B knobs for tools/
+    static const int wgs_env = cf_knob("CATFISH_BF16_WGS") ? atoi(cf_knob("CATFISH_BF16_WGS")) : 0;
     const int waves = waves_env > 0 ? std::min(waves_env, 8) : pick_waves(2 * n_tiles32, m->n_cu);
     const int groups = (n_tiles32 + waves - 1) / waves;           // one workgroup pass = one 32-window tile per wave
     int per_dir = m->n_cu / 2 > 0 ? m->n_cu / 2 : 1;
@@ -1396,7 +1415,7 @@ static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
     if (rc != CF_OK) return rc;
-    static const int pipe_env = getenv("CATFISH_BF16_PIPE") ? atoi(getenv("CATFISH_BF16_PIPE")) : 1;   // A/B knob for tools/
+    static const int pipe_env = cf_knob("CATFISH_BF16_PIPE") ? atoi(cf_knob("CATFISH_BF16_PIPE")) : 1;   // A/B knob for tools/
     if constexpr (NP == 1) {
         if (pipe_env) {      // plain bf16: the software-pipelined kernel (vector work issued behind every MFMA)
             hipLaunchKernelGGL((gru_bf16_pipe_kernel<CIN, LAST>), dim3(gx, 2), dim3(waves * 64), lds_bytes, s, wpack,
@@ -1438,7 +1457,7 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     const int res_waves = res_split ? 4 : (pick_waves(n_tiles, m->n_cu * 2) > 4 ? 4 : pick_waves(n_tiles, m->n_cu * 2));
     const int res_grid = res_split ? n_tiles : std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
     // throughput mode (fp32): the first two blocks as ONE launch, block 0's output stays in registers
-    static const int res_fuse_env = getenv("CATFISH_RES_FUSE") ? atoi(getenv("CATFISH_RES_FUSE")) : 1;   // A/B knob for tools/
+    static const int res_fuse_env = cf_knob("CATFISH_RES_FUSE") ? atoi(cf_knob("CATFISH_RES_FUSE")) : 1;   // A/B knob for tools/
     const bool res_fused = m->np == 0 && m->hp.n_layers_res >= 2 && res_fuse_env != 0;
     sl.last_res_fused = res_fused && !res_split;       // (latency mode also stores block 0's output, for the debug hook)
     if (res_fused) {
@@ -1570,6 +1589,12 @@ static const char* k_fused_timeout_msg = "a fused biGRU launch timed out waiting
 extern "C" int cf_check_error(cf_model* m) {
     if (!m) return fail(CF_ERR_INVALID, "cf_check_error: null model");
     if (m->h_err && *m->h_err) return fail(CF_ERR_HIP, k_fused_timeout_msg);
+    return CF_OK;
+}
+
+extern "C" int cf_clear_error(cf_model* m) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_clear_error: null model");
+    if (m->h_err) *m->h_err = 0u;       // every fused launch re-initialises its own queues and flags: nothing else is stale
     return CF_OK;
 }
 
@@ -2215,4 +2240,5 @@ extern "C" int64_t cf_workspace_bytes(const cf_model* m) { return m ? m->ws_byte
 extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
 #include "chunks_host.hpp"
 
-extern "C" const char* cf_version(void) { return "catfish_hip 0.2 (gfx950; fp32 MFMA 16x16x4, bf16 / bf16x3 MFMA 32x32x16)"; }
+extern "C" int cf_abi_version(void) { return CF_ABI_VERSION; }
+extern "C" const char* cf_version(void) { return "catfish_hip 0.3 (gfx950; fp32 MFMA 16x16x4, bf16 / bf16x3 MFMA 32x32x16)"; }

@@ -2,7 +2,7 @@
 // Included by catfish_hip.hip after cf_model, fail(), HIP_TRY, prof_begin / prof_end.
 #pragma once
 
-static bool gen_forced() { return getenv("CATFISH_GENERIC") && atoi(getenv("CATFISH_GENERIC")) != 0; }     // A/B and test knob, read per model
+static bool gen_forced() { return cf_knob("CATFISH_GENERIC") && atoi(cf_knob("CATFISH_GENERIC")) != 0; }     // A/B and test knob, read per model
 
 static bool gen_wanted(const cf_hparams* hp) {
     return gen_forced() || hp->layer_size != CF_H || (hp->n_layers_res > 0 && hp->layer_size_res != CF_C);
@@ -167,11 +167,11 @@ static int gen_build(cf_model* m, const cf_weights* w) {
     g->h_via_y = per_wave * 8 > (size_t)(160 * 1024);
     if (g->h_via_y) per_wave = (size_t)2 * g->H16 * 64 * sizeof(f32x4);
     g->gru_waves = per_wave * 8 <= (size_t)(160 * 1024) ? 8 : 4;
-    if (getenv("CATFISH_GEN_WAVES")) g->gru_waves = std::max(1, std::min(g->gru_waves, atoi(getenv("CATFISH_GEN_WAVES"))));    // A/B knob for tools/
+    if (cf_knob("CATFISH_GEN_WAVES")) g->gru_waves = std::max(1, std::min(g->gru_waves, atoi(cf_knob("CATFISH_GEN_WAVES"))));    // A/B knob for tools/
     g->gru_lds = per_wave * g->gru_waves;
     // two tiles per wave (gen_gru2_kernel): two LDS arrays per tile; 8 or 4 waves per workgroup, else not used
     const size_t per_wave2 = (size_t)2 * 2 * g->H16 * 64 * sizeof(f32x4);
-    g->gru2_waves = (g->H16 % 4) != 0 || getenv("CATFISH_GEN_ONE_TILE") ? 0 : (per_wave2 * 8 <= (size_t)(160 * 1024) ? 8 : (per_wave2 * 4 <= (size_t)(160 * 1024) ? 4 : 0));
+    g->gru2_waves = (g->H16 % 4) != 0 || cf_knob("CATFISH_GEN_ONE_TILE") ? 0 : (per_wave2 * 8 <= (size_t)(160 * 1024) ? 8 : (per_wave2 * 4 <= (size_t)(160 * 1024) ? 4 : 0));
     g->gru2_lds = per_wave2 * g->gru2_waves;
     if (g->gru2_waves)
         HIP_TRY(hipFuncSetAttribute((const void*)gen_gru2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->gru2_lds));

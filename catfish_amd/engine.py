@@ -84,6 +84,11 @@ class HipEngine(object):
         """Raise if an earlier asynchronous launch of this model reported a device-side error (call after a sync)."""
         N.check(self._lib.cf_check_error(self._handle))
 
+    def clear_error(self):
+        """Reset the sticky device-side error after the results of the failed launch have been dropped (``cf_clear_error``):
+        the engine is usable again."""
+        N.check(self._lib.cf_clear_error(self._handle))
+
     def launch_regimes(self):
         """Switch points of the launcher (windows): dict(n_cu, hoist_max, coop_max, fuse_auto_min)."""
         out = (C.c_int64 * 4)()

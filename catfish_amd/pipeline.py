@@ -156,15 +156,19 @@ class ReadPipeline(object):
         ``as_lists=False`` skips the per-read Python lists and returns the span table as arrays
         ``(read_index, start - 11, end + 16, read_lengths)`` (what a high-rate consumer wants)."""
         t.done.synchronize()
-        self.eng.check_error()                                   # asynchronous launches of this batch: device-side errors are sticky
-        n_s, n_e = (int(v) for v in t.counts_h.tolist())
-        if n_s != n_e or n_s > t.max_runs:
-            raise RuntimeError("cf_spans returned %d starts / %d ends (capacity %d)" % (n_s, n_e, t.max_runs))
-        self.inflight[t.keep[-1]] = None
-        starts = np.sort(t.starts_h[:n_s].numpy())               # np.sort copies out of the pinned slot
-        ends = np.sort(t.ends_h[:n_e].numpy())
-        t.keep = None
-        t.starts = t.ends = t.counts = None
+        try:
+            self.eng.check_error()                               # asynchronous launches of this batch (a device-side error is
+            n_s, n_e = (int(v) for v in t.counts_h.tolist())     # sticky until engine.clear_error())
+            if n_s != n_e or n_s > t.max_runs:
+                raise RuntimeError("cf_spans returned %d starts / %d ends (capacity %d)" % (n_s, n_e, t.max_runs))
+            starts = np.sort(t.starts_h[:n_s].numpy())           # np.sort copies out of the pinned slot
+            ends = np.sort(t.ends_h[:n_e].numpy())
+        finally:
+            # the slot is free again and the batch's device buffers are released whether or not its results were good: a
+            # failed batch must not leave the pipeline claiming "too many batches in flight" on the next submit
+            self.inflight[t.keep[-1]] = None
+            t.keep = None
+            t.starts = t.ends = t.counts = None
         if not as_lists:
             read_of = np.searchsorted(t.s_off, starts, side="right") - 1
             base = t.s_off[read_of]

@@ -36,6 +36,10 @@ extern "C" {
 
 #define CF_WINDOW 35          /* rnn_class.py:27 (self.window) */
 
+/* Bumped whenever a signature or a struct of this header changes; cf_abi_version() returns the value the library was built
+ * with, so a binding can refuse a stale libcatfish_hip.so instead of calling it with the wrong arguments. */
+#define CF_ABI_VERSION 3
+
 /* Arithmetic of the biGRU layers (the residual blocks, the hidden state, the gates'
  * sigmoid/tanh and all accumulation are fp32 in every mode). */
 #define CF_PREC_FP32 0        /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32); default            */
@@ -125,6 +129,9 @@ int cf_infer_host_logits(cf_model* m, const float* x, int64_t n_windows, float* 
  * synchronising the stream a cf_infer was queued on; CF_OK, or CF_ERR_HIP with the message in
  * cf_last_error().  cf_infer / cf_infer_host also refuse to run while it is set. */
 int cf_check_error(cf_model* m);
+/* Reset that flag after the caller has dropped the results of the failed launch: the model is usable again (a fused
+ * launch re-initialises its queues and flags every time; nothing else is stale). */
+int cf_clear_error(cf_model* m);
 
 /* Launch-regime switch points of this model on its device, for callers and tests that need to know which
  * kernels a call of n_windows uses (all in windows):
@@ -311,6 +318,7 @@ int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host);
 int64_t cf_workspace_bytes(const cf_model* m);
 const char* cf_last_error(void);
 const char* cf_version(void);
+int cf_abi_version(void);
 
 #ifdef __cplusplus
 }

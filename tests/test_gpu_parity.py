@@ -289,6 +289,7 @@ def test_any_size_two_tile_kernel_is_bit_identical_to_the_one_tile_kernel(h, c, 
     x = np.random.default_rng(h).normal(0, 1.3, size=(n, 35)).astype(np.float32)
     kw = dict(layer_size=h, n_layers=n_layers, layer_size_res=max(c, 16), n_layers_res=n_layers_res, device=0, max_windows_per_pass=16384)
     two = HipEngine(w, **kw)
+    monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")          # the library reads its A/B knobs only behind this switch
     monkeypatch.setenv("CATFISH_GEN_ONE_TILE", "1")
     one = HipEngine(w, **kw)
     monkeypatch.delenv("CATFISH_GEN_ONE_TILE")
@@ -311,6 +312,7 @@ def test_any_size_path_agrees_with_the_tuned_kernels_on_the_checkpoint(ckpt_weig
     from catfish_amd.engine import HipEngine
     x = np.random.default_rng(21).normal(0, 1.5, size=(354, 35)).astype(np.float32)
     tuned = HipEngine(ckpt_weights, device=0, max_windows_per_pass=1024)
+    monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")          # the library reads its A/B knobs only behind this switch
     monkeypatch.setenv("CATFISH_GENERIC", "1")
     try:
         generic = HipEngine(ckpt_weights, device=0, max_windows_per_pass=1024)

@@ -472,6 +472,17 @@ def test_streaming_pipeline_matches_oracle(model, ckpt_weights):
     assert flat == [sp for spans, _ in got[:3] for sp in spans] and list(ln) == lens[:3]
     with pytest.raises(ValueError):
         pipe.submit([np.zeros(7000, np.int16), np.zeros(7000, np.int16)])     # several reads beyond the batch size
+    # a batch whose results are bad (here: run counts that disagree) frees its slot; the pipeline keeps working
+    for _ in range(pipe.depth + 1):
+        t = pipe.submit(batches[0])
+        t.done.synchronize()
+        t.counts_h[0] += 1
+        with pytest.raises(RuntimeError, match="starts"):
+            pipe.collect(t)
+        assert t.keep is None and all(x is None for x in pipe.inflight)
+    assert [r for res in pipe.run(batches) for r in res] == got
+    model.engine.clear_error()                                 # no error pending: a no-op that must succeed
+    model.engine.check_error()
     # ONE read longer than the batch size grows the staging buffers instead (a directory may hold such a read)
     long_dac = oracle.synthetic_dac(1, 20000, seed=77)[0]
     (spans, n), = pipe.collect(pipe.submit([long_dac]))
@@ -902,7 +913,7 @@ def test_cli_two_ranks_share_one_gpu(tmp_path, ckpt_weights):
     env = dict(os.environ, CATFISH_DEVICE="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     # `catfish --gpus 2`: the CLI starts torch.distributed.run (--nproc-per-node 2 -m catfish_amd.cli ...) as a child process
-    env["MASTER_PORT"] = "29533"
+    env.pop("MASTER_PORT", None)                      # the launcher picks a free rendezvous port
     cmd = [sys.executable, "-m", "catfish_amd.cli", "-i", str(reads), "-s", str(tmp_path / "out"), "-c", "300", "--gpus", "2"]
     res = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          universal_newlines=True, timeout=500)

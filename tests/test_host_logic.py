@@ -351,7 +351,7 @@ def test_missing_library_fails_loudly(hp):
             "    m.initialize_network(seed=0)\n"
             "except _native.NativeLibraryMissing as e:\n"
             "    print('MODEL', type(e).__name__)\n" % (dict(hp),))
-    env = dict(os.environ, CATFISH_HIP_LIB="/nonexistent/libcatfish_hip.so")
+    env = dict(os.environ, CATFISH_HIP_LIB="/nonexistent/libcatfish_hip.so", CATFISH_DEBUG_KNOBS="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "LIB NativeLibraryMissing" in out.stdout and "MODEL NativeLibraryMissing" in out.stdout

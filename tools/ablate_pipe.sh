@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only ablation variants of the pipelined bf16 biGRU kernel -> tools/abl/libcatfish_pipe_abl<bits>.so
 # (CF_PIPE_ABL bits: 1 no activation arithmetic, 2 no MFMA, 4 no A-fragment LDS reads, 8 no global loads/stores).
-# Load one with CATFISH_HIP_LIB=tools/abl/libcatfish_pipe_ablN.so python bench.py --precision bf16 ... (results are wrong by construction)
+# Load one with CATFISH_DEBUG_KNOBS=1 CATFISH_HIP_LIB=tools/abl/libcatfish_pipe_ablN.so python bench.py --precision bf16 ... (results are wrong by construction)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/abl

@@ -34,7 +34,7 @@ def main():
                                 (128, 64, 3, 2, False), (128, 128, 2, 4, False), (256, 128, 3, 2, False), (256, 256, 5, 5, False)):
         w = oracle.random_weights(seed=1, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr)
         if force:
-            os.environ["CATFISH_GENERIC"] = "1"
+            os.environ["CATFISH_DEBUG_KNOBS"] = os.environ["CATFISH_GENERIC"] = "1"
         eng = HipEngine(w, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr, device=0, max_windows_per_pass=n)
         os.environ.pop("CATFISH_GENERIC", None)
         reps = 3 if h >= 128 else 10

@@ -1,5 +1,5 @@
 """Diagnostic: segment timing of the latency-mode fp32 biGRU kernel (library built with -DCF_COOP_STAMP=1).
-usage:  CATFISH_HIP_LIB=tools/abl/libcatfish_coop_stamp.so python tools/exp_coop_stamps.py [n_windows]"""
+usage:  CATFISH_DEBUG_KNOBS=1 CATFISH_HIP_LIB=tools/abl/libcatfish_coop_stamp.so python tools/exp_coop_stamps.py [n_windows]"""
 import ctypes as C
 import os
 import sys

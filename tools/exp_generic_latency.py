@@ -7,7 +7,7 @@ from oracle import catfish_oracle as oracle
 
 for h, c in ((32, 16), (64, 32), (128, 64), (256, 128)):
     w = oracle.random_weights(seed=1, layer_size=h, layer_size_res=c)
-    os.environ["CATFISH_GENERIC"] = "1"
+    os.environ["CATFISH_DEBUG_KNOBS"] = os.environ["CATFISH_GENERIC"] = "1"
     eng = HipEngine(w, layer_size=h, n_layers=3, layer_size_res=c, n_layers_res=2, device=0, max_windows_per_pass=4096)
     os.environ.pop("CATFISH_GENERIC", None)
     res = dict(layer_size=h, layer_size_res=c)

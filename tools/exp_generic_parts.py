@@ -19,7 +19,7 @@ def main():
         geoms = (tuple(int(v) for v in os.environ["GEN"].split(",")),)
     for h, c, nl, nr in geoms:
         w = oracle.random_weights(seed=1, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr)
-        os.environ["CATFISH_GENERIC"] = "1"
+        os.environ["CATFISH_DEBUG_KNOBS"] = os.environ["CATFISH_GENERIC"] = "1"
         eng = HipEngine(w, layer_size=h, n_layers=nl, layer_size_res=c, n_layers_res=nr, device=0, max_windows_per_pass=n)
         os.environ.pop("CATFISH_GENERIC", None)
         for _ in range(2):

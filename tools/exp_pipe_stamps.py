@@ -3,7 +3,7 @@
 Needs a library built with -DCF_PIPE_STAMP=1 (tools/abl/libcatfish_pipe_stamp.so): every non-LAST kernel writes, per
 wave, the s_memtime cycles it spent in phases P1..P4 of all 35 steps, its total and its start/end stamps into the
 dense-partial buffer (the LAST layer writes no partials in such a build, so the mid layer's stamps survive).
-usage:  CATFISH_HIP_LIB=tools/abl/libcatfish_pipe_stamp.so python tools/exp_pipe_stamps.py
+usage:  CATFISH_DEBUG_KNOBS=1 CATFISH_HIP_LIB=tools/abl/libcatfish_pipe_stamp.so python tools/exp_pipe_stamps.py
 """
 import os
 import sys

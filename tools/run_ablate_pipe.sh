@@ -2,7 +2,7 @@
 # GPU box: time the bf16 bench with every ablation variant in tools/abl/ (kernel times from the live HIP events)
 cd "$GRAFT_REPO_ROOT"
 for f in catfish_amd/csrc/libcatfish_hip.so tools/abl/*.so; do
-  CATFISH_HIP_LIB=$PWD/$f python bench.py --precision bf16 --no-cpu-baseline --no-extra-precisions --no-sharded-leg --steps 30 2>/dev/null | python -c "
+  CATFISH_DEBUG_KNOBS=1 CATFISH_HIP_LIB=$PWD/$f python bench.py --precision bf16 --no-cpu-baseline --no-extra-precisions --no-sharded-leg --steps 30 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['kernels_ms']
