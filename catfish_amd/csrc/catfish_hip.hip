@@ -1457,9 +1457,40 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
     const int res_waves = res_split ? 4 : (pick_waves(n_tiles, m->n_cu * 2) > 4 ? 4 : pick_waves(n_tiles, m->n_cu * 2));
     const int res_grid = res_split ? n_tiles : std::min((n_tiles + res_waves - 1) / res_waves, m->n_cu * 4);
     // throughput mode (fp32): the first two blocks as ONE launch, block 0's output stays in registers
-    static const int res_fuse_env = cf_knob("CATFISH_RES_FUSE") ? atoi(cf_knob("CATFISH_RES_FUSE")) : 1;   // A/B knob for tools/
+    const int res_fuse_env = cf_knob("CATFISH_RES_FUSE") ? atoi(cf_knob("CATFISH_RES_FUSE")) : 1;   // A/B knob for tools/ and tests, read per pass
     const bool res_fused = m->np == 0 && m->hp.n_layers_res >= 2 && res_fuse_env != 0;
-    sl.last_res_fused = res_fused && !res_split;       // (latency mode also stores block 0's output, for the debug hook)
+    const bool res_fused_bf16 = m->np > 0 && m->hp.n_layers_res >= 2 && res_fuse_env != 0;
+    sl.last_res_fused = (res_fused && !res_split) || res_fused_bf16;       // (fp32 latency mode also stores block 0's output, for the debug hook)
+    if (res_fused_bf16) {
+        // blocks 0 and 1 as one launch on the bf16 matrix pipe; positions cut into chunks for about four waves per SIMD
+        if ((rc = prof_begin(m, SLOT_RES_STACK2, s, &pi)) != CF_OK) return rc;
+        // bf16: two tiles per wave (every LDS read of a weight fragment or bias vector feeds two tiles: the kernel is bound
+        // by LDS bandwidth), two waves per SIMD; bf16x3: one tile per wave (twice the fragments), two waves per SIMD
+        const int np = m->np > 1 ? 2 : 1;
+        const int tpw = cf_knob("CATFISH_RES_TPW") ? atoi(cf_knob("CATFISH_RES_TPW")) : 1;       // A/B knob for tools/
+        const int groups = (n_tiles32 + tpw - 1) / tpw;
+        const int slots = (np == 1 && tpw == 1 ? 4 * CF_RES_BF16_WAVES : 8) * m->n_cu;          // wave tasks resident at once on the whole chip
+        // as many chunks as keep every task resident in ONE round (a second, mostly empty round costs a whole chunk's chain)
+        int chunks = std::max(1, std::min(CF_T, slots / std::max(1, groups)));
+        if (cf_knob("CATFISH_RES_CHUNKS")) chunks = std::max(1, std::min(CF_T, atoi(cf_knob("CATFISH_RES_CHUNKS"))));   // A/B knob for tools/
+        const int len = (CF_T + chunks - 1) / chunks;
+        chunks = (CF_T + len - 1) / len;
+        const int lds_bytes = rb_pack_bytes(true, np) + rb_pack_bytes(false, np) + 4 * tpw * 32 * CF_T * 4;
+        const int per_cu = std::max(1, std::min(np == 1 && tpw == 1 ? CF_RES_BF16_WAVES : 2, (160 * 1024) / lds_bytes));
+        const int gridb = std::min((groups * chunks + 3) / 4, m->n_cu * per_cu);
+        bf16x8* yb = reinterpret_cast<bf16x8*>(sl.d_a[1]);
+        if (np == 2)
+            hipLaunchKernelGGL((res_stack2_bf16_kernel<2, 1>), dim3(gridb), dim3(256), lds_bytes, s, m->d_res_b[0], m->d_res_b[1], x, yb,
+                               n_windows, n_tiles32, chunks);
+        else if (tpw == 2)
+            hipLaunchKernelGGL((res_stack2_bf16_kernel<1, 2>), dim3(gridb), dim3(256), lds_bytes, s, m->d_res_b[0], m->d_res_b[1], x, yb,
+                               n_windows, n_tiles32, chunks);
+        else
+            hipLaunchKernelGGL((res_stack2_bf16_kernel<1, 1>), dim3(gridb), dim3(256), lds_bytes, s, m->d_res_b[0], m->d_res_b[1], x, yb,
+                               n_windows, n_tiles32, chunks);
+        HIP_TRY(hipGetLastError());
+        if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
+    }
     if (res_fused) {
         if ((rc = prof_begin(m, SLOT_RES_STACK2, s, &pi)) != CF_OK) return rc;
         // latency mode: chunks of positions, one wave each, spread over the idle CUs (about four waves per CU in all)
@@ -1481,7 +1512,7 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         HIP_TRY(hipGetLastError());
         if ((rc = prof_end(m, s, pi)) != CF_OK) return rc;
     }
-    for (int b = res_fused ? 2 : 0; b < m->hp.n_layers_res; ++b) {
+    for (int b = (res_fused || res_fused_bf16) ? 2 : 0; b < m->hp.n_layers_res; ++b) {
         float* dst = sl.d_a[b & 1];
         if (m->np > 0) {
             // residual blocks on the bf16 matrix pipe, 32-window tiles

@@ -370,6 +370,229 @@ __global__ __launch_bounds__(256) void res_block_bf16_kernel(const char* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Residual blocks 0 AND 1 in one launch on the bf16 matrix pipe (resnet_class.py:17-25,44-82), the bf16 counterpart of
+// res_stack2_kernel.  Block 1 runs one position behind block 0 in the same stream: block 0's output is rounded to bf16
+// in registers -- exactly the fragments res_block_bf16_kernel<true> would have stored and <false> re-loaded, so the
+// result is bit-identical to the two launches -- and never exists in HBM (128 B per sample of traffic and a launch
+// less).  The two launches ran one wave per 32-window tile: 944 waves on 1024 SIMDs walking 36 serial positions with
+// nothing to overlap the LDS / MFMA / conversion latencies (matrix pipe busy 9-12 %).  Here a tile's 35 positions are cut
+// into `t_chunks` chunks, one wave each (a chunk starts two positions early and ends one late to rebuild the k = 3
+// neighbourhoods of both blocks); the launcher picks as many chunks as still fit the chip in one round of resident waves.
+// A single read's conv stack is then a few positions deep instead of 2 x 35 (50 -> 11.5 us).
+// Instruction diet (per position and tile, bf16: ~300 -> ~175 VALU): relu after rounding on packed bf16 pairs
+// (v_pk_max_i16), fp32 relu as v_max_i32, conversions in pairs, packed fp32 fma / add, fragments carried as dwords, rings of
+// three fragments in an unrolled-by-three loop instead of register shifts.  Measured (profiles/r03_res_bf16_sweep.json):
+// 256 reads 73.9 -> 51.8 us, 131 072 windows 234 -> 149 us.  TPW = 2 (two tiles per wave: every LDS read of a weight
+// fragment or bias vector feeds two MFMAs) halves the LDS traffic but needs 237 VGPRs (two waves per SIMD) and measured
+// 7 % slower; it stays behind the CATFISH_RES_TPW debug knob.
+// LDS: both blocks' blobs (rb_pack_bytes) + TPW x tiles [32][35] fp32 per wave.
+// ------------------------------------------------------------------------------------------
+#ifndef CF_RES_BF16_WAVES
+#define CF_RES_BF16_WAVES 3            // waves per SIMD the one-tile bf16 kernel is compiled for (131 VGPRs; 4 would spill 5 dwords)
+#endif
+template <int NP, int TPW>
+__global__ __launch_bounds__(256, (NP == 1 && TPW == 1) ? CF_RES_BF16_WAVES : 2) void res_stack2_bf16_kernel(
+    const char* __restrict__ wpack0, const char* __restrict__ wpack1,
+    const float* __restrict__ x_nat,    // [n_windows, 35]
+    bf16x8* __restrict__ y_out,         // block 1's output
+    int64_t n_windows, int n_tiles, int t_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PACK0 = rb_pack_bytes(true, NP), PACK1 = rb_pack_bytes(false, NP);
+    {
+        const f32x4* src0 = reinterpret_cast<const f32x4*>(wpack0);
+        const f32x4* src1 = reinterpret_cast<const f32x4*>(wpack1);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < PACK0 / 16; i += blockDim.x) dst[i] = src0[i];
+        for (int i = threadIdx.x; i < PACK1 / 16; i += blockDim.x) dst[PACK0 / 16 + i] = src1[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hh = lane >> 5;
+    const int nwaves = blockDim.x >> 6;
+    const char* base = reinterpret_cast<const char*>(lds);
+    const bf16x8* WU0 = reinterpret_cast<const bf16x8*>(base) + lane;            // block 0: units {c3 tap0, tap1, tap2, last}
+    const bf16x8* WU1 = reinterpret_cast<const bf16x8*>(base + PACK0) + lane;    // block 1: units {sc, first, c3 tap0, tap1, tap2, last}
+    const char* vbase0 = base + rb_vec_off(true, NP) + hh * 64;                  // {b_c3, b_last, w_sc, b_sc, w_first, b_first}
+    const char* vbase1 = base + PACK0 + rb_vec_off(false, NP) + hh * 64;         // {b_sc, b_first, b_c3, b_last}
+    float* xs = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PACK0 + PACK1) + wave * (TPW * 32 * CF_T);
+
+    typedef u32x4 frag[2][NP];                                                   // 32 features of 32 windows: 2 k-blocks x NP parts of 8 bf16
+    auto vec = [&](const char* vb, int v) -> f32x16 {
+        f32x16 o;
+        const f32x4* p = reinterpret_cast<const f32x4*>(vb + v * 128);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 b = p[c4];
+            o[4 * c4 + 0] = b.x; o[4 * c4 + 1] = b.y; o[4 * c4 + 2] = b.z; o[4 * c4 + 3] = b.w;
+        }
+        return o;
+    };
+    // one conv unit on the wave's TPW tiles: every A fragment is read from LDS once and feeds TPW MFMAs
+    auto unit = [&](const bf16x8* WU, int u, const frag (&in)[TPW], f32x16 (&acc)[TPW]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 a[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = WU[((u * 2 + kb) * NP + p) * 64];
+#pragma unroll
+            for (int w = 0; w < TPW; ++w) {
+                bf16x8 b[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(bf16x8, in[w][kb][p]);
+                acc[w] = prod<NP>(a, b, acc[w]);
+            }
+        }
+    };
+    auto zero_frag = [&](frag (&f)[TPW]) {
+#pragma unroll
+        for (int w = 0; w < TPW; ++w)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) f[w][kb][p] = (u32x4){0u, 0u, 0u, 0u};
+    };
+    auto copy_frag = [&](frag (&d)[TPW], const frag (&s)[TPW]) {
+#pragma unroll
+        for (int w = 0; w < TPW; ++w)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) d[w][kb][p] = s[w][kb][p];
+    };
+
+    const int chunk_len = (CF_T + t_chunks - 1) / t_chunks;
+    const int n_groups = (n_tiles + TPW - 1) / TPW;                              // TPW consecutive tiles per wave
+    for (int task = blockIdx.x * nwaves + wave; task < n_groups * t_chunks; task += gridDim.x * nwaves) {
+        const int group = task / t_chunks;
+        const int tile0 = group * TPW;
+        const int p0 = (task - group * t_chunks) * chunk_len;                    // this wave writes positions [p0, p1)
+        const int p1 = min(p0 + chunk_len, CF_T);
+        if (p0 >= p1) continue;
+        {
+            const int64_t xbase = (int64_t)tile0 * 32 * CF_T;
+            const int64_t limit = n_windows * CF_T;
+            for (int i = lane; i < TPW * 32 * CF_T; i += 64) xs[i] = (xbase + i < limit) ? x_nat[xbase + i] : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // Rings of three fragments instead of shifting registers: block 0's first-conv outputs o1 (ra), block 1's (rb) and block
+        // 0's bf16-rounded output = block 1's input (ry).  Position i writes slot (i - i0) % 3; the loop is unrolled by three so
+        // that every slot is a fixed register range (shifting cost 32 v_mov per position).
+        frag ra[3][TPW], rb[3][TPW], ry[3][TPW];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { zero_frag(ra[r]); zero_frag(rb[r]); zero_frag(ry[r]); }
+        // The shortcut branches are evaluated where they are added (same operations on the same inputs as in the two-launch
+        // kernels, which carry them in registers from the position before): 64 VGPRs less per tile.
+        auto step = [&](int i, const frag (&a_pp)[TPW], const frag (&a_p)[TPW], frag (&a_c)[TPW], const frag (&b_pp)[TPW],
+                        const frag (&b_p)[TPW], frag (&b_c)[TPW], const frag (&y0p)[TPW], frag (&y0)[TPW]) {
+            // ---- block 0, front at position i: Cin = 1, conv1d is a rank-1 update (resnet_class.py:60,64)
+            if (i < CF_T) {
+                const f32x16 w_f = vec(vbase0, 4), b_f = vec(vbase0, 5);
+#pragma unroll
+                for (int w = 0; w < TPW; ++w) {
+                    const float xv = xs[(w * 32 + (lane & 31)) * CF_T + i];
+                    f32x16 xv16;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) xv16[k] = xv;
+                    relu_split16<NP>(__builtin_elementwise_fma(w_f, xv16, b_f), a_c[w]);      // v_pk_fma_f32
+                }
+            } else {
+                zero_frag(a_c);                                                  // zero padding past the window end
+            }
+            // ---- block 0, back: its output at position i - 1, rounded to bf16, stays in registers as block 1's input
+            const bool have_y0 = i >= 1 && i <= CF_T && i >= p0;
+            if (have_y0) {
+                f32x16 acc[TPW], out[TPW];
+                {
+                    const f32x16 b = vec(vbase0, 0);
+#pragma unroll
+                    for (int w = 0; w < TPW; ++w) acc[w] = b;
+                }
+                unit(WU0, 0, a_pp, acc);
+                unit(WU0, 1, a_p, acc);
+                unit(WU0, 2, a_c, acc);
+                frag o2[TPW];
+#pragma unroll
+                for (int w = 0; w < TPW; ++w) relu_split16<NP>(acc[w], o2[w]);
+                {
+                    const f32x16 b = vec(vbase0, 1);
+#pragma unroll
+                    for (int w = 0; w < TPW; ++w) out[w] = b;
+                }
+                unit(WU0, 3, o2, out);
+                {
+                    const f32x16 w_sc = vec(vbase0, 2), b_s = vec(vbase0, 3);
+#pragma unroll
+                    for (int w = 0; w < TPW; ++w) {
+                        const float xp = xs[(w * 32 + (lane & 31)) * CF_T + (i - 1)];
+                        f32x16 xp16;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) xp16[k] = xp;
+                        relu_split16<NP>(relu16_1op(out[w]) + __builtin_elementwise_fma(w_sc, xp16, b_s), y0[w]);   // relu, shortcut, add, relu
+                    }
+                }
+                // ---- block 1, front at position i - 1: first conv + relu
+                {
+                    const f32x16 b = vec(vbase1, 1);
+#pragma unroll
+                    for (int w = 0; w < TPW; ++w) acc[w] = b;
+                }
+                unit(WU1, 1, y0, acc);
+#pragma unroll
+                for (int w = 0; w < TPW; ++w) relu_split16<NP>(acc[w], b_c[w]);
+            } else {
+                zero_frag(b_c);                                                  // before the chunk, or zero padding at t = T
+            }
+            // ---- block 1, back: output position i - 2
+            if (i >= 2 && i - 2 >= p0 && i - 2 < p1) {
+                f32x16 acc[TPW], out[TPW], sc[TPW];
+                {
+                    const f32x16 b = vec(vbase1, 2);
+#pragma unroll
+                    for (int w = 0; w < TPW; ++w) acc[w] = b;
+                }
+                unit(WU1, 2, b_pp, acc);
+                unit(WU1, 3, b_p, acc);
+                unit(WU1, 4, b_c, acc);
+                frag o2[TPW];
+#pragma unroll
+                for (int w = 0; w < TPW; ++w) relu_split16<NP>(acc[w], o2[w]);
+                {
+                    const f32x16 b = vec(vbase1, 3), bs = vec(vbase1, 0);
+#pragma unroll
+                    for (int w = 0; w < TPW; ++w) { out[w] = b; sc[w] = bs; }
+                }
+                unit(WU1, 5, o2, out);
+                unit(WU1, 0, y0p, sc);                                           // shortcut of position i - 2, no relu
+#pragma unroll
+                for (int w = 0; w < TPW; ++w) {
+                    if (tile0 + w >= n_tiles) break;                             // the odd last tile of the call
+                    u32x4 op[2][NP];
+                    relu_split16<NP>(relu16_1op(out[w]) + sc[w], op);                 // relu, add, relu
+                    u32x4* dst = reinterpret_cast<u32x4*>(y_out) + (((int64_t)(tile0 + w) * CF_T + (i - 2)) * 2) * NP * 64 + lane;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) dst[(kb * NP + p) * 64] = op[kb][p];
+                }
+            }
+        };
+        const int i_end = p1 + 1;
+        for (int i = p0 > 2 ? p0 - 2 : 0;; i += 3) {
+            step(i, ra[1], ra[2], ra[0], rb[1], rb[2], rb[0], ry[2], ry[0]);
+            if (i + 1 > i_end) break;
+            step(i + 1, ra[2], ra[0], ra[1], rb[2], rb[0], rb[1], ry[0], ry[1]);
+            if (i + 2 > i_end) break;
+            step(i + 2, ra[0], ra[1], ra[2], rb[0], rb[1], rb[2], ry[1], ry[2]);
+            if (i + 3 > i_end) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- host-side packing -------------------------------------------------------------------
 static inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;

@@ -205,6 +205,46 @@ def test_fused_single_launch_matches_per_layer_launches(ckpt_weights, n_windows)
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_fused_bf16_residual_stack_is_bit_identical_to_two_launches(ckpt_weights, precision, monkeypatch):
+    """res_stack2_bf16_kernel (blocks 0 and 1 in one launch, block 0's bf16-rounded output handed over in registers, a tile's
+    positions cut into chunks of one wave each) against res_block_bf16_kernel<true> + <false> (CATFISH_RES_FUSE=0 behind the
+    debug switch): the same bits at every call size -- one chunk per position (a single read), a few positions per chunk,
+    the benchmark's launch +- a ragged tile, and a pass big enough for one chunk per tile; then a deeper stack (3 blocks:
+    the third one still runs on the per-block kernel) against the fp64 oracle."""
+    from catfish_amd.engine import HipEngine
+    monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=140000, precision=precision)
+    try:
+        for n in (1, 31, 118, 1000, 4097, 30208 + 7, 131072 + 33):
+            x = np.random.default_rng(n).normal(0, 1.4, size=(n, 35)).astype(np.float32)
+            monkeypatch.delenv("CATFISH_RES_FUSE", raising=False)
+            fused, fused_logits = eng.infer_host(x, return_logits=True)
+            monkeypatch.setenv("CATFISH_RES_FUSE", "0")
+            two, two_logits = eng.infer_host(x, return_logits=True)
+            assert np.array_equal(fused, two) and np.array_equal(fused_logits, two_logits), n
+            assert np.isfinite(fused).all()
+            if precision == "bf16" and n in (31, 4097):                         # the two-tiles-per-wave variant (debug knob)
+                monkeypatch.delenv("CATFISH_RES_FUSE")
+                monkeypatch.setenv("CATFISH_RES_TPW", "2")
+                assert np.array_equal(eng.infer_host(x), two), n
+                monkeypatch.delenv("CATFISH_RES_TPW")
+        monkeypatch.delenv("CATFISH_RES_FUSE", raising=False)
+        x = np.random.default_rng(5).normal(0, 1.4, size=(200, 35)).astype(np.float32)
+        want = oracle.forward(x, ckpt_weights, np.float64)
+        assert np.abs(eng.infer_host(x) - want).max() < (3e-2 if precision == "bf16" else 1e-4)
+    finally:
+        eng.close()
+    w = oracle.random_weights(seed=31, n_layers_res=3)
+    eng = HipEngine(w, n_layers_res=3, device=0, max_windows_per_pass=4096, precision=precision)
+    try:
+        x = np.random.default_rng(6).normal(0, 1.2, size=(333, 35)).astype(np.float32)
+        want = oracle.forward(x, w, np.float64, n_layers_res=3)
+        assert np.abs(eng.infer_host(x) - want).max() < (3e-2 if precision == "bf16" else 1e-4)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("h,c,n_layers,n_layers_res,n", [
     (16, 16, 1, 1, 70), (32, 64, 2, 1, 333), (128, 16, 2, 2, 90), (256, 128, 1, 1, 40), (64, 256, 1, 2, 50),
     (48, 80, 3, 3, 100), (80, 48, 2, 1, 77), (96, 16, 1, 1, 30), (32, 0, 2, 0, 200),
