@@ -388,6 +388,55 @@ __global__ __launch_bounds__(256) void res_block_bf16_kernel(const char* __restr
 // 7 % slower; it stays behind the CATFISH_RES_TPW debug knob.
 // LDS: both blocks' blobs (rb_pack_bytes) + TPW x tiles [32][35] fp32 per wave.
 // ------------------------------------------------------------------------------------------
+// two fp32 -> one dword of two bf16 (round to nearest even): a 2-vector conversion compiles to ONE v_cvt_pk_bf16_f32; sixteen
+// scalar (__bf16) casts in a row come out as sixteen single conversions merged by eight v_perm_b32.  (No inline asm here: the
+// values come straight from MFMA results, and the wait states between an MFMA and a VALU read of its result are inserted by
+// the compiler's hazard recogniser, which cannot see into an asm statement.)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+}
+
+// relu as ONE instruction per element: a float is negative iff its int32 pattern is, so max(bits, 0) as signed integers
+// (v_max_i32) is relu.  fmaxf compiles to two v_max_f32 (IEEE mode first quiets a possible signalling NaN with max(x, x)).
+__device__ __forceinline__ f32x16 relu16_1op(f32x16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float f = v[i];                              // (a copy: bit-casting the vector ELEMENT itself reads element 0 every time)
+        const int b = __builtin_bit_cast(int, f);
+        v[i] = __builtin_bit_cast(float, b > 0 ? b : 0);
+    }
+    return v;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+
+// relu + rounding to bf16 fragments.  One bf16 part: round first, then clamp the PACKED pairs with v_pk_max_i16 against 0 -- a
+// bf16 is negative iff its int16 pattern is, and rounding keeps the sign, so relu(round(v)) == round(relu(v)) bit for bit at
+// half the VALU instructions (8 conversions + 8 packed max instead of 16 max + 8 conversions).  hi + lo split: relu in fp32
+// first.  Fragments are carried as four DWORDS (u32x4), not as eight bf16: across the kernel's branches the compiler otherwise
+// tracks every 16-bit element on its own and re-packs them at each join (v_lshrrev + v_perm_b32, 16 instructions per fragment).
+template <int NP>
+__device__ __forceinline__ void relu_split16(const f32x16& v, u32x4 (&out)[2][NP]) {
+    if constexpr (NP == 1) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const u32x4 d = {cvt_pk_bf16(v[8 * kb + 0], v[8 * kb + 1]), cvt_pk_bf16(v[8 * kb + 2], v[8 * kb + 3]),
+                             cvt_pk_bf16(v[8 * kb + 4], v[8 * kb + 5]), cvt_pk_bf16(v[8 * kb + 6], v[8 * kb + 7])};
+            const i16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            out[kb][0] = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(i16x8, d), z));
+        }
+    } else {
+        bf16x8 parts[2][NP];
+        split16<NP>(relu16_1op(v), parts);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) out[kb][p] = __builtin_bit_cast(u32x4, parts[kb][p]);
+    }
+}
+
 #ifndef CF_RES_BF16_WAVES
 #define CF_RES_BF16_WAVES 3            // waves per SIMD the one-tile bf16 kernel is compiled for (131 VGPRs; 4 would spill 5 dwords)
 #endif
