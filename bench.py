@@ -43,6 +43,7 @@ ACHIEVABLE_HBM_GBS = 6300.0         # what a device-to-device copy sustains on t
 MID_LAYER_BYTES_PER_SAMPLE = {"fp32": 128 * 4 * 2, "bf16": 128 * 2 * 2}   # a CIN = 128 biGRU layer: input slab + output slab
 SHARDED_READS_PER_RANK = 12500      # BASELINE configs[2]: 100 000 reads over 8 GPUs
 CONFIG4_READS = 10000               # BASELINE configs[3]
+CONFIG4_MAX_WINDOWS = 131072        # windows per packed launch: the regime catfish_amd.cli uses for big jobs (cli.run_pipeline)
 CONFIG4_PARITY_READS = 32           # reads of it checked against the fp32 oracle (shortest, longest, 30 spread over the rest)
 
 
@@ -176,7 +177,7 @@ def leg_config4(weights, local_rank, torch):
     rng = np.random.default_rng(2)
     lens = np.rint(np.exp(rng.uniform(np.log(512), np.log(16384), size=CONFIG4_READS))).astype(np.int64)
     dacs = [squiggle_dac(rng, int(n)) for n in lens]
-    max_windows = READS_PER_STEP * 118
+    max_windows = CONFIG4_MAX_WINDOWS
     eng = HipEngine(weights, device=local_rank, max_windows_per_pass=max_windows, precision="bf16")
     dev = torch.device("cuda", local_rank)
     packed = []

@@ -38,6 +38,12 @@
 #ifndef CF_PIPE_NT
 #define CF_PIPE_NT 0
 #endif
+// A/B variants of the vector work (bit-identical results): bit 0 = the update gate's sigmoid is written straight into its
+// accumulator registers (no copies in finish_u); bit 1 = scalar fp32 instructions instead of packed ones; bit 2 = static
+// priority for the second-dispatched half of the workgroup (waves 4-7, the arbitration losers of every SIMD)
+#ifndef CF_PIPE_VAR
+#define CF_PIPE_VAR 0
+#endif
 
 template <int CIN>
 struct gb_pipe {
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(512, 2) void gru_bf16_pipe_kernel(const char* __res
     const f32x4* DW = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_dense_off(CIN, 1)) + hh * 4;
 
     const int nwaves = blockDim.x >> 6;
+    if ((CF_PIPE_VAR & 4) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int tstep = dir ? -1 : 1;                         // bw = reversed time
     const int t0 = dir ? (CF_T - 1) : 0;
     for (int tile = blockIdx.x * nwaves + wave; tile < n_tiles; tile += gridDim.x * nwaves) {
@@ -141,20 +148,30 @@ __global__ __launch_bounds__(512, 2) void gru_bf16_pipe_kernel(const char* __res
             const int m = j >> 3, i = 2 * (j & 7);
             ev[j] = (f32x2){__builtin_amdgcn_exp2f(acc[2 * gate + m][i]), __builtin_amdgcn_exp2f(acc[2 * gate + m][i + 1])};
         };
-        auto stage_r = [&](int j) {
+        auto stage_r = [&](int j, int gate) {
             if (CF_PIPE_ABL & 1) return;
-            const f32x2 d = ev[j] + (f32x2){1.0f, 1.0f};
-            ev[j] = (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            f32x2 d;
+            if (CF_PIPE_VAR & 2) { d.x = ev[j].x + 1.0f; d.y = ev[j].y + 1.0f; }
+            else d = ev[j] + (f32x2){1.0f, 1.0f};
+            if ((CF_PIPE_VAR & 1) && gate == 1) {           // u: the pre-activation is dead, the gate value replaces it in place
+                const int m = j >> 3, i = 2 * (j & 7);
+                acc[2 + m][i] = __builtin_amdgcn_rcpf(d.x);
+                acc[2 + m][i + 1] = __builtin_amdgcn_rcpf(d.y);
+            } else {
+                ev[j] = (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            }
         };
         auto finish_r = [&](int j) {                        // r*h -> bf16 (reset BEFORE the candidate matmul: gru_cell/mul -> concat_1)
             if (CF_PIPE_ABL & 1) return;
             const int m = j >> 3, i = 2 * (j & 7);
-            const f32x2 rh = ev[j] * (f32x2){h[m][i], h[m][i + 1]};
+            f32x2 rh;
+            if (CF_PIPE_VAR & 2) { rh.x = ev[j].x * h[m][i]; rh.y = ev[j].y * h[m][i + 1]; }
+            else rh = ev[j] * (f32x2){h[m][i], h[m][i + 1]};
             rp[j >> 2][2 * (j & 3)] = (__bf16)rh.x;
             rp[j >> 2][2 * (j & 3) + 1] = (__bf16)rh.y;
         };
         auto finish_u = [&](int j) {
-            if (CF_PIPE_ABL & 1) return;
+            if ((CF_PIPE_ABL & 1) || (CF_PIPE_VAR & 1)) return;
             const int m = j >> 3, i = 2 * (j & 7);
             acc[2 + m][i] = ev[j].x;
             acc[2 + m][i + 1] = ev[j].y;
@@ -162,9 +179,15 @@ __global__ __launch_bounds__(512, 2) void gru_bf16_pipe_kernel(const char* __res
         auto finish_h = [&](int j) {                        // h' = u*h + (1-u)*c      (gru_cell/mul_1, sub, mul_2, add)
             if (CF_PIPE_ABL & 1) return;
             const int m = j >> 3, i = 2 * (j & 7);
-            const f32x2 c = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, ev[j], (f32x2){1.0f, 1.0f});
+            f32x2 c, hn;
             const f32x2 u = {acc[2 + m][i], acc[2 + m][i + 1]};
-            const f32x2 hn = __builtin_elementwise_fma(u, (f32x2){h[m][i], h[m][i + 1]} - c, c);
+            if (CF_PIPE_VAR & 2) {
+                c.x = fmaf(-2.0f, ev[j].x, 1.0f); c.y = fmaf(-2.0f, ev[j].y, 1.0f);
+                hn.x = fmaf(u.x, h[m][i] - c.x, c.x); hn.y = fmaf(u.y, h[m][i + 1] - c.y, c.y);
+            } else {
+                c = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, ev[j], (f32x2){1.0f, 1.0f});
+                hn = __builtin_elementwise_fma(u, (f32x2){h[m][i], h[m][i + 1]} - c, c);
+            }
             h[m][i] = hn.x;
             h[m][i + 1] = hn.y;
             hp[j >> 2][2 * (j & 3)] = (__bf16)hn.x;
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gru_bf16_pipe_kernel(const char* __res
 #define CF_STAGES(k, PS, GATE, FIN)                                                       \
     _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                   \
         if (PS(j_) + 2 == (k)) FIN(j_);                                                   \
-        if (PS(j_) + 1 == (k)) stage_r(j_);                                               \
+        if (PS(j_) + 1 == (k)) stage_r(j_, GATE);                                         \
         if (PS(j_) == (k)) stage_e(j_, GATE);                                             \
     }
 

@@ -29,6 +29,8 @@ import ctypes as C
 from catfish_amd import _native as N
 N.check(eng._lib.cf_debug_stage(eng._handle, 100, raw.size, raw.ctypes.data_as(C.c_void_p)))
 st = raw.view(np.int64).reshape(2, n_tiles, 8)
+if len(sys.argv) > 1:
+    np.save(sys.argv[1], st)                     # raw per-wave stamps for offline analysis
 for d, name in ((0, "fw"), (1, "bw")):
     s = st[d]
     tot = s[:, 4]
