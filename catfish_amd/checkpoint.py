@@ -357,8 +357,13 @@ def write_checkpoint(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
     meta_block = _build_block([])
     m_off, m_size = len(table), len(meta_block)
     table += _with_trailer(meta_block)
-    last_key = items[-1][0] + b"\x00"  # separator >= last key
-    index_block = _build_block([(last_key, _put_varint(d_off) + _put_varint(d_size))])
+    # index entry of the (single) data block: leveldb's TableBuilder::Finish stores FindShortSuccessor(last key) -- the
+    # last key cut after its first byte that is not 0xff, that byte incremented ("stack_..." -> "t").  With it the
+    # .index file comes out byte for byte as TensorFlow 1.10 wrote ckpnt-30000.index (tests/test_checkpoint.py).
+    last_key = items[-1][0]
+    cut = next((i for i, b in enumerate(last_key) if b != 0xFF), None)
+    successor = last_key if cut is None else last_key[:cut] + bytes([last_key[cut] + 1])
+    index_block = _build_block([(successor, _put_varint(d_off) + _put_varint(d_size))])
     i_off, i_size = len(table), len(index_block)
     table += _with_trailer(index_block)
     footer = _put_varint(m_off) + _put_varint(m_size) + _put_varint(i_off) + _put_varint(i_size)
