@@ -94,6 +94,9 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
     timings = {} if timings is None else timings
     finished = False
     try:
+        # every host-side exchange of this job (set-up agreement, final gather) goes over gloo, also when the caller's default
+        # group is RCCL: created first, while no rank can have failed yet
+        host_group = sharding.host_gather_group()
         temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
         input_dir = os.path.abspath(input_dir)
         network_path = os.path.abspath(network_path)
@@ -113,7 +116,7 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
                                                 max_windows_per_pass=max_windows, precision=precision)
         except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
             setup_error = exc
-        sharding.agree_or_raise(setup_error, "set-up (output directories, network)")
+        sharding.agree_or_raise(setup_error, "set-up (output directories, network)", group=host_group)
         timings["setup_s"] = (datetime.datetime.now() - t1).total_seconds()
         if rank == 0:
             print("Loaded model in {}".format(datetime.datetime.now() - t1))
@@ -121,7 +124,7 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         t2 = datetime.datetime.now()
         table = sharding.chunk_files_sharded(model, ["{}/{}".format(input_dir, f) for f in input_files], chunk_size,
                                              max_samples_per_batch=max_windows * infer.WINDOW_SIZE,
-                                             gather_group=sharding.host_gather_group(), timings=timings)
+                                             gather_group=host_group, timings=timings)
         if rank == 0:
             print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
             print("Splitting reads...")
