@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gru_bf16_pipe_kernel(const char* __res
             rp[j >> 2][2 * (j & 3) + 1] = (__bf16)rh.y;
         };
         auto finish_u = [&](int j) {
-            if ((CF_PIPE_ABL & 1) || (CF_PIPE_VAR & 1)) return;
+            if ((CF_PIPE_ABL & 1) != 0 || (CF_PIPE_VAR & 1) != 0) return;
             const int m = j >> 3, i = 2 * (j & 7);
             acc[2 + m][i] = ev[j].x;
             acc[2 + m][i + 1] = ev[j].y;
