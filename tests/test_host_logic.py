@@ -355,3 +355,50 @@ def test_missing_library_fails_loudly(hp):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "LIB NativeLibraryMissing" in out.stdout and "MODEL NativeLibraryMissing" in out.stdout
+
+
+def test_library_override_needs_the_debug_switch_and_a_matching_abi(tmp_path):
+    """``CATFISH_HIP_LIB`` is a debug knob: ignored unless ``CATFISH_DEBUG_KNOBS=1`` (a stray variable must not swap the
+    product library), named on stderr when it takes effect, and a library built for another ``CF_ABI_VERSION`` is refused
+    instead of being called with the wrong arguments."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    src = tmp_path / "stale.c"
+    src.write_text("int cf_abi_version(void) { return 2; }\n")
+    stale = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(stale), str(src)], check=True)
+    code = ("from catfish_amd import _native\n"
+            "try:\n"
+            "    _native.lib()\n"
+            "    print('LOADED', _native.LIB_PATH)\n"
+            "except _native.NativeLibraryMissing as e:\n"
+            "    print('REFUSED', e)\n")
+    base = {k: v for k, v in os.environ.items() if k not in ("CATFISH_DEBUG_KNOBS", "CATFISH_HIP_LIB")}
+    quiet = subprocess.run([sys.executable, "-c", code], env=dict(base, CATFISH_HIP_LIB=str(stale)), capture_output=True,
+                           text=True, cwd=ROOT, timeout=300)
+    assert "LOADED " + _native.DEFAULT_LIB_PATH in quiet.stdout and "debug knob" not in quiet.stderr
+    loud = subprocess.run([sys.executable, "-c", code], env=dict(base, CATFISH_HIP_LIB=str(stale), CATFISH_DEBUG_KNOBS="1"),
+                          capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert "REFUSED" in loud.stdout and "ABI 2" in loud.stdout and "needs %d" % _native.CF_ABI_VERSION in loud.stdout
+    assert "debug knob CATFISH_HIP_LIB" in loud.stderr
+
+
+def test_roofline_is_reported_against_the_nearer_roof():
+    """bench.nearer_roof: fp32 mid layer stays on the matrix roof, the bf16 one moves to HBM (by algorithmic bytes: input +
+    output slab; the stored PMC traffic decides a near tie) and keeps the matrix view beside it."""
+    import bench
+    n = 256 * 4096
+    fp32 = {"bound": "mfma", "achieved": 129.4, "peak": 157.3, "unit": "TFLOP/s", "frac": 129.4 / 157.3, "traffic": 1.586e9}
+    out = bench.nearer_roof(dict(fp32), "fp32", n, 1.194e-3)
+    assert out["bound"] == "mfma" and abs(out["hbm_view"]["frac"] - 1024 * n / 1.194e-3 / 8e12) < 1e-9
+    assert abs(out["hbm_view"]["traffic_rate_frac"] - 1.586e9 / 1.194e-3 / 8e12) < 1e-9
+    bf16 = {"bound": "mfma", "achieved": 867.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 867.0 / 2500.0, "traffic": 813.5e6}
+    out = bench.nearer_roof(dict(bf16), "bf16", n, 178.3e-6)
+    assert out["bound"] == "hbm" and out["unit"] == "GB/s" and out["peak"] == 8000.0
+    assert abs(out["frac"] - 512 * n / 178.3e-6 / 8e12) < 1e-9 and out["mfma_view"]["frac"] == bf16["frac"]
+    assert out["hbm_detail"]["traffic_rate_frac"] > out["frac"]            # 1.5x re-read: each direction reads the whole input
+    tie = {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None}
+    assert bench.nearer_roof(dict(tie), "bf16", n, 1e-3)["bound"] == "mfma"   # no traffic record, algorithmic bytes below
