@@ -32,7 +32,7 @@ def _lib_path():
 
 
 LIB_PATH = DEFAULT_LIB_PATH
-CF_ABI_VERSION = 3            # include/catfish_hip.h
+CF_ABI_VERSION = 4            # include/catfish_hip.h
 
 CF_OK = 0
 CF_ERR_INVALID = -1
@@ -98,6 +98,7 @@ SYMBOLS = {
     "cf_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "cf_chunks_from_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "cf_load_npy_int16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     "cf_chunks_json": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64]),
     "cf_gru_pack_map": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),

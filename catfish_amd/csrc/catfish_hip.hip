@@ -2270,6 +2270,7 @@ extern "C" int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* 
 extern "C" int64_t cf_workspace_bytes(const cf_model* m) { return m ? m->ws_bytes : 0; }
 extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
 #include "chunks_host.hpp"
+#include "loader_host.hpp"
 
 extern "C" int cf_abi_version(void) { return CF_ABI_VERSION; }
 extern "C" const char* cf_version(void) { return "catfish_hip 0.3 (gfx950; fp32 MFMA 16x16x4, bf16 / bf16x3 MFMA 32x32x16)"; }

@@ -11,6 +11,7 @@ bench.py's ``value``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -56,6 +57,37 @@ class ReadPipeline(object):
         self.tab = [None] * self.depth                           # pinned offset / length tables per staging slot
         self.k = 0
 
+    def _claim_slot(self):
+        """The staging slot of the next batch, once the H2D copy that last read from it is done."""
+        slot = self.k % self.depth
+        if self.inflight[slot] is not None:
+            raise RuntimeError("ReadPipeline: at most %d batches in flight; collect() the oldest ticket first" % self.depth)
+        self.stage_free[slot].synchronize()                     # previous H2D out of this staging buffer is done
+        return slot
+
+    def submit_files(self, paths, n_threads=4):
+        """Launch one batch straight from files: one-dimensional little-endian int16 ``.npy`` reads (the format
+        ``infer.load_dac`` takes when there is no HDF5) are read by the library's host thread pool (``cf_load_npy_int16``)
+        directly into the pinned staging slot -- no per-file Python, no intermediate arrays.  Returns a ticket, or None when
+        this batch needs the general loader (a file of another kind, or reads that do not fit the staging buffer): nothing
+        has been consumed then."""
+        paths = [os.fsencode(p) for p in paths]
+        if not paths:
+            return None
+        slot = self._claim_slot()
+        blob = b"\x00".join(paths) + b"\x00"
+        bounds = np.zeros(len(paths) + 1, dtype=np.int64)
+        np.cumsum([len(p) + 1 for p in paths], out=bounds[1:])
+        lengths = np.empty(len(paths), dtype=np.int64)
+        total = C.c_int64(0)
+        rc = self.eng._lib.cf_load_npy_int16(blob, bounds.ctypes.data_as(C.c_void_p), len(paths),
+                                             C.c_void_p(self.stage[slot].data_ptr()), self.cap,
+                                             lengths.ctypes.data_as(C.c_void_p), C.byref(total), int(n_threads))
+        if rc != N.CF_OK:
+            return None
+        self.k += 1
+        return self._launch(slot, lengths, int(total.value))
+
     def submit(self, dac_reads):
         """Launch one batch asynchronously; returns a ticket for ``collect``."""
         torch = self.torch
@@ -69,24 +101,27 @@ class ReadPipeline(object):
                 ev.synchronize()
             self.cap = total
             self.stage = [torch.empty(self.cap, dtype=torch.int16, pin_memory=True) for _ in range(self.depth)]
-        dac_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
-        np.cumsum(lengths, out=dac_off[1:])
-        n_win = lengths // WINDOW_SIZE + 1                      # infer.py:32-36: a multiple of 35 gets a full extra window
-        win_off = np.zeros(len(dac_reads) + 1, dtype=np.int64)
-        np.cumsum(n_win, out=win_off[1:])
-        slot = self.k % self.depth
-        if self.inflight[slot] is not None:
-            raise RuntimeError("ReadPipeline: at most %d batches in flight; collect() the oldest ticket first" % self.depth)
+        slot = self._claim_slot()
         self.k += 1
-        self.stage_free[slot].synchronize()                     # previous H2D out of this staging buffer is done
         host = self.stage[slot].numpy()
         if len(dac_reads) == 1:
             host[:total] = dac_reads[0]
         elif total:
             np.concatenate(dac_reads, out=host[:total], casting="unsafe")     # one C call instead of a Python loop over the reads
+        return self._launch(slot, lengths, total)
+
+    def _launch(self, slot, lengths, total):
+        """Everything after staging: tables up, H2D, normalise, forward, post-process, run lists down."""
+        torch = self.torch
+        n_reads = len(lengths)
+        dac_off = np.zeros(n_reads + 1, dtype=np.int64)
+        np.cumsum(lengths, out=dac_off[1:])
+        n_win = lengths // WINDOW_SIZE + 1                      # infer.py:32-36: a multiple of 35 gets a full extra window
+        win_off = np.zeros(n_reads + 1, dtype=np.int64)
+        np.cumsum(n_win, out=win_off[1:])
         # the four small tables go up from PINNED memory too, as one copy: a pageable source makes the runtime pin user
         # pages for the transfer, and host allocator activity (munmap) near such mappings stalls the GPU queues
-        n_r = len(dac_reads)
+        n_r = n_reads
         n_tab = 4 * (n_r + 1)
         if self.tab[slot] is None or self.tab[slot].numel() < n_tab:
             self.tab[slot] = torch.empty(max(n_tab, 1024), dtype=torch.int64, pin_memory=True)

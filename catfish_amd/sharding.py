@@ -289,18 +289,43 @@ class EngineBatchRunner(object):
         """``batches``: iterable of lists of raw reads -> yields per batch, in order, ``[(spans, length)]`` or (``compact``)
         a ``SpanTable`` of the batch."""
         self.compact = bool(compact)
+        return self._drive(self._submit_reads(reads) for reads in batches)
+
+    def run_files(self, path_batches, compact=False):
+        """The same from batches of FILE NAMES: int16 ``.npy`` reads go from disk into the pipeline's pinned staging buffer
+        through the library's host thread pool (``ReadPipeline.submit_files``); a batch that needs the general loader (other
+        formats, or more samples than the size on disk suggested) is loaded with ``infer.load_dac`` and re-cut by its true
+        lengths.  Results come out in the order of the names, one item per submitted batch."""
+        self.compact = bool(compact)
+        from .infer import load_dac
+
+        def items():
+            for paths in path_batches:
+                ticket = self.pipe.submit_files(paths)
+                if ticket is not None:
+                    yield (ticket, None)
+                    continue
+                reads = [load_dac(p) for p in paths]
+                for idx in _batches_by_samples(list(range(len(reads))), [len(r) for r in reads], self.max_samples):
+                    yield self._submit_reads([reads[i] for i in idx])
+        return self._drive(items())
+
+    def _submit_reads(self, reads):
         from . import batching
         from .infer import is_dac, normalize_raw_signal
+        if all(is_dac(r) for r in reads):
+            return (self.pipe.submit([np.ascontiguousarray(r, dtype=np.int16) for r in reads]), None)
+        normed = [normalize_raw_signal(np.asarray(r), "median") for r in reads]
+        max_windows = max(1, self.max_samples // WINDOW_SIZE)
+        return (None, batching.infer_reads(self.engine, normed, max_windows=max_windows,
+                                           threshold=self.threshold, min_run=self.min_run))
+
+    def _drive(self, items):
+        """Up to the pipeline's depth of batches in flight: ``items`` submits lazily (each element is (ticket, host-path results
+        or None)), results are finished in order."""
         from collections import deque
-        pending = deque()        # (ticket, host-path results or None), up to the pipeline's depth in flight
-        for reads in batches:
-            if all(is_dac(r) for r in reads):
-                item = (self.pipe.submit([np.ascontiguousarray(r, dtype=np.int16) for r in reads]), None)
-            else:
-                normed = [normalize_raw_signal(np.asarray(r), "median") for r in reads]
-                max_windows = max(1, self.max_samples // WINDOW_SIZE)
-                item = (None, batching.infer_reads(self.engine, normed, max_windows=max_windows,
-                                                   threshold=self.threshold, min_run=self.min_run))
+        pending = deque()
+        for item in items:
             pending.append(item)
             if len(pending) == self.pipe.depth:
                 yield self._finish(pending.popleft())
@@ -345,11 +370,21 @@ def _prefetched(gen, depth=3):
         yield item
 
 
-def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact):
+def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact, size_hints=None):
     """This rank's device work: the reads ``mine`` (indices into ``reads``) through the batch runner, batches cut at
     ``max_samples_per_batch`` samples, files loaded a bounded number of batches ahead.  ``compact``: a ``SpanTable`` (arrays
-    end to end) instead of ``[(spans, length)]`` lists."""
+    end to end) instead of ``[(spans, length)]`` lists.  ``size_hints`` (estimated samples per item, e.g. from the size on
+    disk): ``reads`` are file names for ``infer.load_dac`` and the runner may read them itself (``run_files``: the library's
+    native loader straight into pinned memory instead of one Python call per file)."""
     runner = batch_runner if batch_runner is not None else EngineBatchRunner(model, max_samples_per_batch)
+    if size_hints is not None and hasattr(runner, "run_files"):
+        path_batches = ([reads[i] for i in idx] for idx in _batches_by_samples(mine, size_hints, max_samples_per_batch))
+        if compact:
+            return SpanTable.concat(list(runner.run_files(path_batches, compact=True)))
+        out = []
+        for res in runner.run_files(path_batches):
+            out.extend(res)
+        return out
 
     def batches():
         if lengths is not None:
@@ -380,7 +415,7 @@ def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch,
 
 
 def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_per_batch=None, batch_runner=None,
-                        rank=None, world_size=None, gather_group=None, costs=None):
+                        rank=None, world_size=None, gather_group=None, costs=None, size_hints=None):
     """Homopolymer spans of many reads, sharded over the ranks of the job; rank 0 gets ``[(spans, length)]``
     in input order, the other ranks get None.
 
@@ -413,7 +448,8 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
             dist.get_world_size() if dist.is_available() and dist.is_initialized() else dist_env()[1])
         # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
         compact = n_ranks > 1 and (batch_runner is None or isinstance(batch_runner, EngineBatchRunner))
-        return _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact)
+        return _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact,
+                               size_hints=size_hints)
 
     from .batching import quiet_gc
     with quiet_gc():
@@ -424,6 +460,12 @@ def _file_costs(paths):
     return [max(1, os.path.getsize(p)) if os.path.exists(p) else 1 for p in paths]
 
 
+def _sample_hints(file_sizes):
+    """Samples per file estimated from its size on disk (int16 behind numpy's usual 128-byte header); only used to cut
+    batches before anything is read -- a batch that turns out too big is re-cut by its true lengths."""
+    return [max(1, (int(c) - 128) // 2) for c in file_sizes]
+
+
 def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=None, rank=None, world_size=None,
                         gather_group=None):
     """The reference's per-file loop (catfish/catfish:50-56), sharded: files are dealt to ranks by size on disk
@@ -431,9 +473,10 @@ def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=N
     ``infer.load_dac`` -- one batch at a time, so host memory does not grow with the directory -- and rank 0
     receives ``[(spans, read length)]`` in the order of ``paths``."""
     from .infer import load_dac
-    return infer_reads_sharded(model, list(paths), lengths=None, load_fn=load_dac, costs=_file_costs(paths),
+    costs = _file_costs(paths)
+    return infer_reads_sharded(model, list(paths), lengths=None, load_fn=load_dac, costs=costs,
                                max_samples_per_batch=max_samples_per_batch, batch_runner=batch_runner,
-                               rank=rank, world_size=world_size, gather_group=gather_group)
+                               rank=rank, world_size=world_size, gather_group=gather_group, size_hints=_sample_hints(costs))
 
 
 def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=None, batch_runner=None, rank=None,
@@ -452,10 +495,13 @@ def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=Non
         max_samples_per_batch = 32768 * WINDOW_SIZE
     timings = {} if timings is None else timings
 
+    costs = _file_costs(paths)
+    hints = _sample_hints(costs)
+
     def work(mine):
         t0 = time.perf_counter()
-        table = _spans_of_shard(model, paths, mine, None, load_dac, max_samples_per_batch, batch_runner, True) \
-            if mine else SpanTable([], [], [], [])
+        table = _spans_of_shard(model, paths, mine, None, load_dac, max_samples_per_batch, batch_runner, True,
+                                size_hints=hints) if mine else SpanTable([], [], [], [])
         t1 = time.perf_counter()
         out = ChunkTable.from_span_table(table, chunk_size)
         timings["infer_s"], timings["chunks_s"] = t1 - t0, time.perf_counter() - t1
@@ -472,5 +518,5 @@ def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=Non
 
     from .batching import quiet_gc
     with quiet_gc():
-        return run_sharded_indexed(_file_costs(paths), work, rank=rank, world_size=world_size, gather_group=gather_group,
+        return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group,
                                    partition="contiguous", assemble=assemble)

@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes; cf_abi_version() returns the value the library was built
  * with, so a binding can refuse a stale libcatfish_hip.so instead of calling it with the wrong arguments. */
-#define CF_ABI_VERSION 3
+#define CF_ABI_VERSION 4
 
 /* Arithmetic of the biGRU layers (the residual blocks, the hidden state, the gates'
  * sigmoid/tanh and all accumulation are fp32 in every mode). */
@@ -196,6 +196,17 @@ int cf_chunks_from_spans(const int64_t* span_bounds, const int64_t* span_start, 
  * capacity of sum(key bytes) + 48 per row + 40 per read always suffices). */
 int64_t cf_chunks_json(const char* keys, const int64_t* key_bounds, int64_t n_reads, const int64_t* bounds,
                        const int64_t* start, const int64_t* end, const uint8_t* whole_read, char* out, int64_t capacity);
+
+/* Ingest on the HOST (no device work, no cf_model): the file read of the reference's per-file loop (catfish/catfish:50-56 ->
+ * infer.process_signal, infer.py:77-93) for the read format this image can hold -- one-dimensional C-order little-endian
+ * int16 .npy files (DAC codes after the leader trim; there is no HDF5 library here) -- for MANY files at once: a pool of
+ * n_threads host threads (<= 0: 4) reads them straight into ONE caller-owned buffer, back to back in the order given.
+ * paths: the names as NUL-terminated strings back to back, path_bounds[n_files + 1] their byte offsets; out / capacity: the
+ * int16 buffer (e.g. pinned staging memory) and its size in samples; lengths[n_files] receives every read's sample count,
+ * *total (may be NULL) their sum (also when they do not fit capacity).  CF_ERR_INVALID names the first file that is
+ * missing or is not such an array in cf_last_error(): the caller then takes its general loader for that batch. */
+int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
+                      int64_t* lengths, int64_t* total, int32_t n_threads);
 
 /* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
  * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,

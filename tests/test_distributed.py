@@ -306,6 +306,10 @@ def _small_oracle_runner():
                 res = [infer_read(r) for r in reads]
                 yield sharding.SpanTable.from_lists(res) if compact else res
 
+        def run_files(self, path_batches, compact=False):          # the product reads the files natively into pinned memory
+            from catfish_amd.infer import load_dac
+            return self.run(([load_dac(p) for p in paths] for paths in path_batches), compact)
+
     return Runner, infer_read
 
 

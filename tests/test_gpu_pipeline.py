@@ -1,4 +1,5 @@
 """GPU tests of the read-level pipeline and of full-size properties (through the C ABI)."""
+import json
 import os
 
 import numpy as np
@@ -890,6 +891,51 @@ def test_sharded_runner_world1_real_engine(model, ckpt_weights, tmp_path):
     for (spans, n), f in zip(got_f, flt):
         w_spans, w_n, _ = oracle.infer_read(oracle.normalize_raw_signal(f), ckpt_weights, np.float32)
         assert (spans, n) == (w_spans, w_n)
+
+
+def test_files_go_through_the_native_loader_and_fall_back_per_batch(model, ckpt_weights, tmp_path, monkeypatch):
+    """sharding.infer_files_sharded / chunk_files_sharded on the real engine: int16 .npy reads are read by the library's
+    thread pool straight into the pipeline's pinned staging buffer (ReadPipeline.submit_files); a batch holding another
+    format (.npz, float .npy) or more samples than its size on disk suggested goes through infer.load_dac -- same results
+    either way, in the order of the file names."""
+    from catfish_amd import chunks, cli, sharding
+    from catfish_amd.pipeline import ReadPipeline
+    lens = [4096, 36, 700, 35, 140, 999, 70, 512, 64, 300, 2000, 3333, 37, 4096, 9000]
+    dacs = [oracle.synthetic_dac(1, max(n, 2), seed=400 + i)[0][:n] for i, n in enumerate(lens)]
+    paths = []
+    for i, d in enumerate(dacs):
+        if i == 5:
+            p = tmp_path / ("r%02d.npz" % i)
+            np.savez(p, raw=d)                                   # the reference's NPZ layout: general loader
+        elif i == 9:
+            p = tmp_path / ("r%02d.npy" % i)
+            np.save(p, d.astype(np.int64))                       # integer codes in another dtype: general loader
+        else:
+            p = tmp_path / ("r%02d.npy" % i)
+            np.save(p, d)
+        paths.append(str(p))
+    want = []
+    for d in dacs:
+        spans, n, _ = oracle.infer_read(oracle.normalize_raw_signal(d), ckpt_weights, np.float32)
+        want.append((spans, n))
+    calls = {"native": 0, "fallback": 0}
+    real = ReadPipeline.submit_files
+
+    def counted(self, batch, n_threads=4):
+        t = real(self, batch, n_threads)
+        calls["native" if t is not None else "fallback"] += 1
+        return t
+
+    monkeypatch.setattr(ReadPipeline, "submit_files", counted)
+    got = sharding.infer_files_sharded(model, paths, max_samples_per_batch=6000)      # several batches, one oversize read
+    assert got == want
+    assert calls["native"] >= 3 and calls["fallback"] >= 2                            # both kinds of batch occurred
+    table = sharding.chunk_files_sharded(model, paths, chunk_size=300, max_samples_per_batch=6000)
+    hp, nonhp = table.to_dicts(paths)
+    for p, (spans, n) in zip(paths, want):
+        merged, non = cli.chunks_of_read([list(s) for s in spans], n, 300)
+        assert hp.get(p) == merged and json.dumps(nonhp[p]) == json.dumps(non)
+    assert isinstance(table, chunks.ChunkTable) and list(table.lengths) == lens
 
 
 @pytest.mark.timeout(600)

@@ -402,3 +402,55 @@ def test_roofline_is_reported_against_the_nearer_roof():
     assert out["hbm_detail"]["traffic_rate_frac"] > out["frac"]            # 1.5x re-read: each direction reads the whole input
     tie = {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None}
     assert bench.nearer_roof(dict(tie), "bf16", n, 1e-3)["bound"] == "mfma"   # no traffic record, algorithmic bytes below
+
+
+def test_native_npy_loader_reads_what_the_python_loader_reads(tmp_path):
+    """cf_load_npy_int16 (host code of the C-ABI library: a pool of threads reading int16 .npy reads straight into one
+    buffer) against infer.load_dac on the same files; everything else is refused with the file named, so that the caller
+    takes the general loader -- never a silent misread."""
+    import ctypes as C
+    lib = _native.lib()
+    rng = np.random.default_rng(3)
+
+    def call(paths, capacity, threads=4):
+        enc = [os.fsencode(str(p)) for p in paths]
+        blob = b"\x00".join(enc) + b"\x00"
+        bounds = np.concatenate(([0], np.cumsum([len(e) + 1 for e in enc]))).astype(np.int64)
+        out = np.full(max(capacity, 1), -7, dtype=np.int16)
+        lengths = np.full(len(paths), -1, dtype=np.int64)
+        total = C.c_int64(-1)
+        rc = lib.cf_load_npy_int16(blob, bounds.ctypes.data_as(C.c_void_p), len(paths), out.ctypes.data_as(C.c_void_p), capacity,
+                                   lengths.ctypes.data_as(C.c_void_p), C.byref(total), threads)
+        return rc, out, lengths, int(total.value), lib.cf_last_error().decode()
+
+    reads, paths = [], []
+    for i, n in enumerate([4096, 0, 1, 35, 70000, 513] + [int(v) for v in rng.integers(1, 3000, size=60)]):
+        r = rng.integers(-2000, 2047, size=n).astype(np.int16)
+        p = tmp_path / ("r%03d.npy" % i)
+        np.save(p, r)
+        reads.append(r)
+        paths.append(p)
+    want = np.concatenate(reads)
+    for threads in (1, 4, 0, 200):
+        rc, out, lengths, total, _ = call(paths, len(want) + 10, threads)
+        assert rc == 0 and total == len(want) and np.array_equal(lengths, [len(r) for r in reads])
+        assert np.array_equal(out[:total], want) and (out[total:] == -7).all()
+    for p, r in zip(paths, reads):
+        assert np.array_equal(infer.load_dac(str(p)), r)
+    # does not fit: refused, the needed size reported, nothing promised about the buffer
+    rc, _out, _l, total, msg = call(paths, len(want) - 1)
+    assert rc == _native.CF_ERR_INVALID and total == len(want) and "fit" in msg
+    # files the general loader must take: other dtype, two dimensions, Fortran order, truncated, missing, not an .npy at all
+    bad = {}
+    np.save(tmp_path / "f32.npy", np.zeros(8, np.float32)); bad["f32.npy"] = True
+    np.save(tmp_path / "i4.npy", np.zeros(8, np.int32)); bad["i4.npy"] = True
+    np.save(tmp_path / "two_d.npy", np.zeros((4, 2), np.int16)); bad["two_d.npy"] = True
+    np.save(tmp_path / "big_endian.npy", np.zeros(8, ">i2")); bad["big_endian.npy"] = True
+    buf = open(paths[0], "rb").read()
+    open(tmp_path / "short.npy", "wb").write(buf[:-2]); bad["short.npy"] = True
+    open(tmp_path / "text.npy", "wb").write(b"hello"); bad["text.npy"] = True
+    bad["missing.npy"] = True
+    for name in bad:
+        rc, _out, _l, _t, msg = call([paths[0], tmp_path / name, paths[2]], 100000)
+        assert rc == _native.CF_ERR_INVALID and name in msg, name
+    assert call([], 0)[0] == 0
