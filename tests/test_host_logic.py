@@ -261,12 +261,12 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads and exports exactly what include/catfish_hip.h declares (no compute calls)."""
     import re
     header = open(os.path.join(ROOT, "include", "catfish_hip.h")).read()
-    declared = set(re.findall(r"\b(cf_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_native.SYMBOLS)
     assert os.path.exists(_native.LIB_PATH), "run `python -m catfish_amd.build` first"
     out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], stdout=subprocess.PIPE,
                          universal_newlines=True, check=True).stdout
-    exported = set(re.findall(r" T (cf_[a-z_]+)", out))
+    exported = set(re.findall(r" T (cf_[a-z0-9_]+)", out))
     assert declared <= exported
     lib = _native.lib()
     assert b"gfx950" in lib.cf_version()
