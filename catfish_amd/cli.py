@@ -100,14 +100,17 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
         input_dir = os.path.abspath(input_dir)
         network_path = os.path.abspath(network_path)
-        model = input_files = max_windows = None
+        model = input_files = file_sizes = max_windows = None
         t1 = datetime.datetime.now()
         setup_error = None
         try:
             if rank == 0:
                 os.makedirs("{}/HP".format(temp_dir))      # raises if they exist, like the reference (:37-38)
                 os.mkdir("{}/nonHP".format(temp_dir))
-            input_files = sorted(os.listdir(input_dir))
+            with os.scandir(input_dir) as scan:            # names and sizes in one pass over the directory
+                listing = sorted((entry.name, entry.stat().st_size) for entry in scan)
+            input_files = [name for name, _size in listing]
+            file_sizes = [size for _name, size in listing]
             # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
             # tail instead of 8 % and the three layers go out as one dynamically scheduled launch.
             max_windows = 131072 if len(input_files) > 400 * world else 32768
@@ -124,7 +127,7 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         t2 = datetime.datetime.now()
         table = sharding.chunk_files_sharded(model, ["{}/{}".format(input_dir, f) for f in input_files], chunk_size,
                                              max_samples_per_batch=max_windows * infer.WINDOW_SIZE,
-                                             gather_group=host_group, timings=timings)
+                                             gather_group=host_group, timings=timings, file_sizes=file_sizes)
         if rank == 0:
             print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
             print("Splitting reads...")

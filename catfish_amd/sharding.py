@@ -457,7 +457,14 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
 
 
 def _file_costs(paths):
-    return [max(1, os.path.getsize(p)) if os.path.exists(p) else 1 for p in paths]
+    """Size on disk of every file (1 for a missing one: the loader reports it when its turn comes) -- one stat each."""
+    out = []
+    for p in paths:
+        try:
+            out.append(max(1, os.stat(p).st_size))
+        except OSError:
+            out.append(1)
+    return out
 
 
 def _sample_hints(file_sizes):
@@ -480,13 +487,14 @@ def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=N
 
 
 def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=None, batch_runner=None, rank=None,
-                        world_size=None, gather_group=None, timings=None):
+                        world_size=None, gather_group=None, timings=None, file_sizes=None):
     """The WHOLE per-file loop body of the reference (catfish/catfish:55-82) sharded: a rank classifies its files and
     also merges / centres / complements their spans (``chunks.ChunkTable``: one native call over the rank's span table),
     so what travels to rank 0 is six small arrays per rank and what rank 0 does is concatenate them.  Files go to ranks
     in contiguous blocks of near-equal size on disk (``shard_contiguous``), so the gathered tables are already in the order
     of ``paths``.  -> ``ChunkTable`` over all files on rank 0, None elsewhere.  ``timings``: optional dict that receives this
-    rank's ``infer_s`` / ``chunks_s`` and, on rank 0, ``assemble_s``."""
+    rank's ``infer_s`` / ``chunks_s`` and, on rank 0, ``assemble_s``.  ``file_sizes``: the files' sizes on disk when the caller
+    has them already (a directory scan yields them for free; otherwise one ``stat`` per file here)."""
     import time
     from .chunks import ChunkTable
     from .infer import load_dac
@@ -495,7 +503,9 @@ def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=Non
         max_samples_per_batch = 32768 * WINDOW_SIZE
     timings = {} if timings is None else timings
 
-    costs = _file_costs(paths)
+    costs = [max(1, int(c)) for c in file_sizes] if file_sizes is not None else _file_costs(paths)
+    if len(costs) != len(paths):
+        raise ValueError("file_sizes must hold one size per path")
     hints = _sample_hints(costs)
 
     def work(mine):
