@@ -352,8 +352,8 @@ def leg_sharded_gather(eng, weights, rank, world, dist, torch):
 def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
     """The product entry point on BASELINE configs[2]'s shape, files -> JSON: ``catfish_amd.cli.run_pipeline`` (the body of
     catfish/catfish:23-94 up to the split step) over a directory of 12 500 x 4096-sample int16 reads per rank.  Every rank
-    loads, classifies AND merges / centres / complements its own files (catfish/catfish:50-82); rank 0 gathers the chunk
-    tables, formats and writes the two JSON documents.  Timed from the end of set-up (network loaded on every rank) to the
+    loads, classifies AND merges / centres / complements its own files (catfish/catfish:50-82), formats its part of the two
+    JSON documents and writes it at its offset.  Timed from the end of set-up (network loaded on every rank) to the
     documents on disk; page cache warm (the files were just written)."""
     import contextlib
     import io
@@ -385,8 +385,8 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
         failure = None
         try:
             with contextlib.redirect_stdout(sink):            # the pipeline prints the reference's progress lines
-                table = cli.run_pipeline(os.path.join(root, "reads"), os.path.join(root, "out"), chunk_size=1000,
-                                         network_path=os.path.join(root, "ResNetRNN"), device=local_rank, timings=timings)
+                res = cli.run_pipeline(os.path.join(root, "reads"), os.path.join(root, "out"), chunk_size=1000,
+                                       network_path=os.path.join(root, "ResNetRNN"), device=local_rank, timings=timings)
         except Exception as exc:                              # noqa: BLE001 -- raised below, after the barrier every rank reaches
             failure = exc
         total = time.perf_counter() - t0
@@ -397,20 +397,22 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
         if rank != 0:
             return None
         dt = total - timings["setup_s"]
-        post = timings.get("assemble_s", 0.0) + timings.get("write_s", 0.0)
+        post = timings.get("write_s", 0.0)
         with open(os.path.join(root, "out", "TEMP", "hp_positions.json")) as fh:
             hp = json.load(fh)
-        ok = len(table) == n_total and bool((table.lengths == READ_LEN).all()) and 0 < len(hp) <= n_total
+        with open(os.path.join(root, "out", "TEMP", "nonhp_positions.json")) as fh:
+            nonhp = json.load(fh)
+        ok = (res["reads"] == n_total == len(nonhp) and res["samples"] == n_total * READ_LEN
+              and len(hp) == res["reads_with_hp"] and sum(len(v) for v in hp.values()) == res["hp_chunks"])
         return {"workload": "configs[2] through the CLI: %d files x %d samples (seed 1) over %d rank(s), %d per rank; chunk_size "
                             "1000" % (n_total, READ_LEN, world, SHARDED_READS_PER_RANK),
                 "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "set_up_seconds": timings["setup_s"],
-                "rank0": {"infer_s": timings.get("infer_s"), "chunks_s": timings.get("chunks_s"),
-                          "assemble_s": timings.get("assemble_s"), "write_s": timings.get("write_s")},
-                "rank0_post_gather_frac": post / dt, "reads": n_total, "reads_with_hp": len(hp),
-                "hp_chunks": int(table.hp_bounds[-1]), "n_gpus": world, "results_ok": bool(ok),
+                "rank0": {"infer_s": timings.get("infer_s"), "chunks_s": timings.get("chunks_s"), "write_s": timings.get("write_s")},
+                "rank0_after_classification_frac": post / dt, "reads": n_total, "reads_with_hp": len(hp),
+                "hp_chunks": res["hp_chunks"], "document_bytes": res["bytes"], "n_gpus": world, "results_ok": bool(ok),
                 "what": "int16 .npy files -> per-rank loader thread + ReadPipeline (cf_normalize, cf_infer, cf_postprocess, cf_spans) "
-                        "-> per-rank cf_chunks_from_spans (merge, center_hp, complement) -> gloo gather of chunk tables -> rank 0 "
-                        "cf_chunks_json + write; never the headline value"}
+                        "-> per-rank cf_chunks_from_spans (merge, center_hp, complement) -> per-rank cf_chunks_json, every rank writes its "
+                        "part of the two documents at its offset (no result gather); never the headline value"}
     finally:
         if rank == 0:
             shutil.rmtree(root, ignore_errors=True)

@@ -75,27 +75,31 @@ def chunks_of_read(hp_positions, len_read, chunk_size=1000):
 
 
 def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN", network_type="ResNetRNN",
-                 checkpoint=30000, device=None, precision="fp32", timings=None):
+                 checkpoint=30000, device=None, precision="fp32", timings=None, gather_table=False):
     """Body of the reference's ``main`` (catfish/catfish:23-94) up to the split step.
 
     Under ``torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the per-file loop of
-    catfish/catfish:50-82 is sharded WITH its tail: every rank loads and classifies its own files on its own MI355X and
-    merges / centres / complements their spans (``sharding.chunk_files_sharded``); rank 0 receives the ranks' chunk
-    tables over a gloo group, concatenates them and writes the two JSON documents (formatted natively from the arrays).
-    Returns a ``chunks.ChunkTable`` with a ``names`` attribute on rank 0 (``.to_dicts(table.names)`` gives the reference's
-    ``hp_dict`` / ``nonhp_dict``) and None on the other ranks.  Files are taken in sorted order (the reference iterates in
-    ``os.listdir`` order, which is arbitrary), so N ranks write the same bytes as one.  ``timings`` (optional dict) receives
-    this rank's ``setup_s``, ``infer_s``, ``chunks_s`` and on rank 0 ``assemble_s`` / ``write_s``.
+    catfish/catfish:50-82 is sharded WITH its tail, and so is the writing: every rank reads and classifies its own block of
+    the (sorted) file list on its own MI355X, merges / centres / complements the spans (``sharding.chunk_files_local``),
+    formats its part of the two JSON documents and writes it at its offset (``chunks.write_json_documents``).  The ranks
+    exchange three small objects over a gloo group -- set-up status, shard status, byte counts -- and no results at all;
+    rank 0 does nothing that grows with the number of ranks.  Files are taken in sorted order (the reference iterates in
+    ``os.listdir`` order, which is arbitrary), so N ranks write the same bytes as one.
+
+    Returns on every rank the totals ``dict(reads, samples, reads_with_hp, hp_chunks, bytes, files)``; with
+    ``gather_table=True`` rank 0's dict also holds ``table``: the ``chunks.ChunkTable`` over all files gathered from the
+    ranks (``table.to_dicts(files)`` = the reference's ``hp_dict`` / ``nonhp_dict``).  ``timings`` (optional dict) receives
+    this rank's ``setup_s``, ``infer_s``, ``chunks_s``, ``write_s``.
     """
     import time
-    from . import sharding
+    from . import chunks, sharding
     rank, world, local_rank = sharding.dist_env()
     own_group = sharding.init_host_group()
     timings = {} if timings is None else timings
     finished = False
     try:
-        # every host-side exchange of this job (set-up agreement, final gather) goes over gloo, also when the caller's default
-        # group is RCCL: created first, while no rank can have failed yet
+        # every host-side exchange of this job goes over gloo, also when the caller's default group is RCCL: created
+        # first, while no rank can have failed yet
         host_group = sharding.host_gather_group()
         temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
         input_dir = os.path.abspath(input_dir)
@@ -125,23 +129,34 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
             print("Loaded model in {}".format(datetime.datetime.now() - t1))
             print("Checking for homopolymers in raw signal..")
         t2 = datetime.datetime.now()
-        table = sharding.chunk_files_sharded(model, ["{}/{}".format(input_dir, f) for f in input_files], chunk_size,
-                                             max_samples_per_batch=max_windows * infer.WINDOW_SIZE,
-                                             gather_group=host_group, timings=timings, file_sizes=file_sizes)
+        mine = table = shard_error = None
+        try:
+            mine, table = sharding.chunk_files_local(model, ["{}/{}".format(input_dir, f) for f in input_files], chunk_size,
+                                                     max_samples_per_batch=max_windows * infer.WINDOW_SIZE, rank=rank,
+                                                     world_size=world, timings=timings, file_sizes=file_sizes)
+        except Exception as exc:                          # noqa: BLE001 -- a bad file on one rank fails the whole job, at once
+            shard_error = exc
+        sharding.agree_or_raise(shard_error, "classification", group=host_group)
         if rank == 0:
             print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
             print("Splitting reads...")
-            t3 = time.perf_counter()
-            table.names = input_files
-            hp_text, nonhp_text = table.json_members(input_files)
-            for name, text in (("hp_positions.json", hp_text), ("nonhp_positions.json", nonhp_text)):
-                with open(os.path.join(temp_dir, name), "wb") as fh:
-                    fh.write(b"{" + text + b"}")
-            timings["write_s"] = time.perf_counter() - t3
+        t3 = time.perf_counter()
+        result = chunks.write_json_documents(temp_dir, table, [input_files[i] for i in mine], group=host_group)
+        timings["write_s"] = time.perf_counter() - t3
+        result["files"] = input_files
+        if rank == 0:
             print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
                 temp_dir, datetime.timedelta(seconds=timings["write_s"])))
+        if gather_table:
+            import torch.distributed as dist
+            if world > 1:
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(table, parts, dst=0, group=host_group)
+                table = chunks.ChunkTable.concat(parts) if rank == 0 else None
+            if rank == 0:
+                result["table"] = table
         finished = True
-        return table
+        return result
     finally:
         if own_group:
             import torch.distributed as dist

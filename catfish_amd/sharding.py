@@ -486,35 +486,64 @@ def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=N
                                rank=rank, world_size=world_size, gather_group=gather_group, size_hints=_sample_hints(costs))
 
 
-def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=None, batch_runner=None, rank=None,
-                        world_size=None, gather_group=None, timings=None, file_sizes=None):
-    """The WHOLE per-file loop body of the reference (catfish/catfish:55-82) sharded: a rank classifies its files and
-    also merges / centres / complements their spans (``chunks.ChunkTable``: one native call over the rank's span table),
-    so what travels to rank 0 is six small arrays per rank and what rank 0 does is concatenate them.  Files go to ranks
-    in contiguous blocks of near-equal size on disk (``shard_contiguous``), so the gathered tables are already in the order
-    of ``paths``.  -> ``ChunkTable`` over all files on rank 0, None elsewhere.  ``timings``: optional dict that receives this
-    rank's ``infer_s`` / ``chunks_s`` and, on rank 0, ``assemble_s``.  ``file_sizes``: the files' sizes on disk when the caller
-    has them already (a directory scan yields them for free; otherwise one ``stat`` per file here)."""
+def chunk_files_local(model, paths, chunk_size=1000, max_samples_per_batch=None, batch_runner=None, rank=None,
+                      world_size=None, timings=None, file_sizes=None):
+    """This rank's share of the reference's per-file loop body (catfish/catfish:55-82), NO collective: the files are cut into
+    ``world_size`` contiguous blocks of near-equal size on disk (``shard_contiguous``), this rank classifies block ``rank`` and
+    merges / centres / complements its spans (``chunks.ChunkTable``: one native call over the rank's span table).
+    -> (indices of my files in ``paths`` -- a contiguous range --, their ChunkTable).  ``timings``: optional dict that receives
+    ``infer_s`` / ``chunks_s``.  ``file_sizes``: sizes on disk when the caller has them already (a directory scan yields them for
+    free; otherwise one ``stat`` per file here)."""
     import time
     from .chunks import ChunkTable
     from .infer import load_dac
     paths = list(paths)
     if max_samples_per_batch is None:
         max_samples_per_batch = 32768 * WINDOW_SIZE
-    timings = {} if timings is None else timings
-
+    env_rank, env_world, _local = dist_env()
+    rank = env_rank if rank is None else int(rank)
+    world_size = env_world if world_size is None else int(world_size)
     costs = [max(1, int(c)) for c in file_sizes] if file_sizes is not None else _file_costs(paths)
     if len(costs) != len(paths):
         raise ValueError("file_sizes must hold one size per path")
-    hints = _sample_hints(costs)
-
-    def work(mine):
+    mine = shard_contiguous(costs, world_size)[rank]
+    from .batching import quiet_gc
+    with quiet_gc():
         t0 = time.perf_counter()
         table = _spans_of_shard(model, paths, mine, None, load_dac, max_samples_per_batch, batch_runner, True,
-                                size_hints=hints) if mine else SpanTable([], [], [], [])
+                                size_hints=_sample_hints(costs)) if mine else SpanTable([], [], [], [])
         t1 = time.perf_counter()
         out = ChunkTable.from_span_table(table, chunk_size)
+    if timings is not None:
         timings["infer_s"], timings["chunks_s"] = t1 - t0, time.perf_counter() - t1
+    if len(out) != len(mine):
+        raise RuntimeError("chunk_files_local: %d results for %d files" % (len(out), len(mine)))
+    return mine, out
+
+
+def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=None, batch_runner=None, rank=None,
+                        world_size=None, gather_group=None, timings=None, file_sizes=None):
+    """``chunk_files_local`` on every rank + a host gather: what travels to rank 0 is six small arrays per rank and what rank 0
+    does is concatenate them (the blocks are contiguous, so the gathered tables are already in the order of ``paths``).
+    -> ``ChunkTable`` over all files on rank 0, None elsewhere.  ``timings`` also receives ``assemble_s`` on rank 0.  A caller
+    that only needs the documents written (the CLI) skips this gather altogether: ``cli.run_pipeline``."""
+    import time
+    from .chunks import ChunkTable
+    paths = list(paths)
+    timings = {} if timings is None else timings
+    costs = [max(1, int(c)) for c in file_sizes] if file_sizes is not None else _file_costs(paths)
+    if len(costs) != len(paths):
+        raise ValueError("file_sizes must hold one size per path")
+
+    def work(mine):
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized()
+        r = rank if rank is not None else (dist.get_rank() if distributed else 0)
+        w = world_size if world_size is not None else (dist.get_world_size() if distributed else 1)
+        got, out = chunk_files_local(model, paths, chunk_size, max_samples_per_batch, batch_runner, rank=r, world_size=w,
+                                     timings=timings, file_sizes=costs)
+        if got != list(mine):
+            raise RuntimeError("chunk_files_sharded: shard mismatch")
         return out
 
     def assemble(gathered):
@@ -526,7 +555,5 @@ def chunk_files_sharded(model, paths, chunk_size=1000, max_samples_per_batch=Non
         timings["assemble_s"] = time.perf_counter() - t0
         return out
 
-    from .batching import quiet_gc
-    with quiet_gc():
-        return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group,
-                                   partition="contiguous", assemble=assemble)
+    return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group,
+                               partition="contiguous", assemble=assemble)

@@ -337,8 +337,10 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
     cli.neural_network.load_network = load_network
     t0 = time.time()
     try:
-        table = cli.run_pipeline(os.path.join(tmpdir, "reads"), os.path.join(tmpdir, out_name), chunk_size=300)
-        outcome = "returned %s" % (None if table is None else len(table))
+        res = cli.run_pipeline(os.path.join(tmpdir, "reads"), os.path.join(tmpdir, out_name), chunk_size=300,
+                               gather_table=(out_name == "out8"))
+        table = res.get("table")
+        outcome = "returned %d reads, table %s" % (res["reads"], None if table is None else len(table))
     except Exception as exc:                                               # noqa: BLE001 -- recorded for the parent
         outcome = "%s %s" % (type(exc).__name__, exc)
     open(os.path.join(tmpdir, "%s.rank%d" % (out_name, rank)), "w").write("%.1f %s" % (time.time() - t0, outcome))
@@ -346,8 +348,9 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
 
 @pytest.mark.timeout(300)
 def test_eight_ranks_write_the_same_bytes_as_one(tmp_path):
-    """catfish -i -s over 8 gloo ranks vs 1: every rank classifies AND merges its own reads (native chunk tables), rank 0
-    concatenates and writes -- byte-identical documents, equal to the per-read Python rules on the per-read results."""
+    """catfish -i -s over 8 gloo ranks vs 1: every rank classifies AND merges its own reads (native chunk tables) and writes
+    its own part of the two documents at its offset -- byte-identical documents, equal to the per-read Python rules on the
+    per-read results; some ranks hold no read with a homopolymer chunk, or no read at all."""
     import json
     import torch.multiprocessing as mp
     from catfish_amd import cli
@@ -355,8 +358,9 @@ def test_eight_ranks_write_the_same_bytes_as_one(tmp_path):
     _write_reads(str(tmp_path / "reads"), n_reads)
     mp.spawn(_pipeline_worker, args=(8, _free_port(), str(tmp_path), n_reads, "out8", None), nprocs=8, join=True)
     mp.spawn(_pipeline_worker, args=(1, _free_port(), str(tmp_path), n_reads, "out1", None), nprocs=1, join=True)
-    assert (tmp_path / "out8.rank0").read_text().endswith("returned %d" % n_reads)
-    assert all((tmp_path / ("out8.rank%d" % r)).read_text().endswith("returned None") for r in range(1, 8))
+    assert (tmp_path / "out8.rank0").read_text().endswith("returned %d reads, table %d" % (n_reads, n_reads))   # gather_table=True
+    assert all((tmp_path / ("out8.rank%d" % r)).read_text().endswith("returned %d reads, table None" % n_reads) for r in range(1, 8))
+    assert (tmp_path / "out1.rank0").read_text().endswith("returned %d reads, table None" % n_reads)
     docs = {}
     for out in ("out8", "out1"):
         docs[out] = [(tmp_path / out / "TEMP" / f).read_bytes() for f in ("hp_positions.json", "nonhp_positions.json")]
@@ -371,7 +375,7 @@ def test_eight_ranks_write_the_same_bytes_as_one(tmp_path):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("what", ["directories", "network"])
+@pytest.mark.parametrize("what", ["directories", "network", "file"])
 def test_a_rank_that_fails_during_set_up_fails_the_job_at_once(tmp_path, what):
     """a failure BEFORE the data path (rank 0: the split directory exists, catfish/catfish:37-38; any rank:
     the network does not load) used to leave the failing rank in a barrier and the others in the gather until the group
@@ -380,13 +384,18 @@ def test_a_rank_that_fails_during_set_up_fails_the_job_at_once(tmp_path, what):
     _write_reads(str(tmp_path / "reads"), 4)
     if what == "directories":
         os.makedirs(tmp_path / "out" / "TEMP" / "HP")
+    if what == "file":                                   # the last file (rank 1's block) is not a read
+        (tmp_path / "reads" / "read_zzz.npy").write_bytes(b"not a numpy file")
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 4, "out", what), nprocs=2, join=True)
     r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
     assert float(r0[0]) < 30 and float(r1[0]) < 30
     if what == "directories":
         assert r0[1].startswith("FileExistsError") and r1[1].startswith("RuntimeError") and "rank 0: FileExistsError" in r1[1]
-    else:
+    elif what == "network":
         assert r1[1].startswith("ValueError") and r0[1].startswith("RuntimeError") and "rank 1: ValueError" in r0[1]
+    else:
+        assert not r1[1].startswith("returned") and r0[1].startswith("RuntimeError") and "classification failed on rank 1" in r0[1]
+        assert not (tmp_path / "out" / "TEMP" / "hp_positions.json").exists()      # nothing half-written
 
 
 def test_contiguous_shards_tile_in_order_and_balance():
