@@ -169,11 +169,13 @@ class SpanTable(object):
 
     def expand(self):
         """-> [(spans, length)] per read, the reference's return values (one ``tolist`` + one slice per read)."""
+        from .batching import quiet_gc
         n = len(self)
-        pairs = np.stack([self.start, self.end], axis=1).tolist()
-        bounds = np.concatenate(([0], np.cumsum(np.bincount(self.read_of, minlength=n)[:n]))).tolist()
-        lens = self.lengths.tolist()
-        return [(pairs[bounds[r]:bounds[r + 1]], lens[r]) for r in range(n)]
+        with quiet_gc():          # ~20 small lists per read: with the cyclic collector on, every 700 of them walk the whole process
+            pairs = np.stack([self.start, self.end], axis=1).tolist()
+            bounds = np.concatenate(([0], np.cumsum(np.bincount(self.read_of, minlength=n)[:n]))).tolist()
+            lens = self.lengths.tolist()
+            return [(pairs[bounds[r]:bounds[r + 1]], lens[r]) for r in range(n)]
 
 
 def run_sharded_indexed(costs, work_fn, rank=None, world_size=None, gather_group=None, partition="lpt", assemble=None):
