@@ -454,3 +454,41 @@ def test_native_npy_loader_reads_what_the_python_loader_reads(tmp_path):
         rc, _out, _l, _t, msg = call([paths[0], tmp_path / name, paths[2]], 100000)
         assert rc == _native.CF_ERR_INVALID and name in msg, name
     assert call([], 0)[0] == 0
+
+
+def test_native_chunk_rules_property_based():
+    """Property test (hypothesis) of cf_chunks_from_spans + cf_chunks_json against the per-read Python rules: arbitrary
+    ascending span lists (overlapping, touching, negative starts, ends past the read), chunk sizes from 1 up, read lengths
+    shorter than a chunk -- the integer quirks of catfish/catfish:57-82,121-135 must agree on every input, through the JSON
+    text (i.e. including the `[([(0, len), len])]` and `[]` forms)."""
+    import copy
+    import json
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+    from catfish_amd import chunks
+
+    span = st.tuples(st.integers(-30, 6000), st.integers(1, 3000))
+    read = st.tuples(st.lists(span, min_size=0, max_size=12), st.integers(1, 7000))
+
+    @hyp.settings(max_examples=300, deadline=None)
+    @hyp.given(st.lists(read, min_size=1, max_size=6), st.integers(1, 2500))
+    def check(reads, chunk_size):
+        fixed = []
+        for spans, length in reads:
+            starts = sorted(s for s, _n in spans)
+            fixed.append(([[s, s + n] for s, (_s, n) in zip(starts, spans)], length))
+        names = ["r%d" % i for i in range(len(fixed))]
+        want_hp, want_non = {}, {}
+        for name, (spans, length) in zip(names, fixed):
+            merged, non = cli.chunks_of_read(copy.deepcopy(spans), length, chunk_size)
+            if merged is not None:
+                want_hp[name] = merged
+            want_non[name] = non
+        bounds = np.concatenate(([0], np.cumsum([len(sp) for sp, _n in fixed])))
+        flat = np.array([p for sp, _n in fixed for p in sp], dtype=np.int64).reshape(-1, 2)
+        tab = chunks.ChunkTable.from_spans(bounds, flat[:, 0], flat[:, 1], [n for _sp, n in fixed], chunk_size)
+        hp_text, non_text = tab.json_members(names)
+        assert b"{" + hp_text + b"}" == json.dumps(want_hp).encode()
+        assert b"{" + non_text + b"}" == json.dumps(want_non).encode()
+
+    check()
