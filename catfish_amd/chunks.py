@@ -167,7 +167,8 @@ def write_json_documents(directory, table, names, group=None):
     rank ``pwrite``s its members -- preceded by ``", "`` when an earlier rank wrote any -- at its offset.  The files are byte
     for byte what one rank would have written (``{`` + members joined by ``", "`` + ``}``: ``json.dump`` of the reference's
     ``hp_dict`` / ``nonhp_dict``), and rank 0 does nothing that grows with the number of ranks: formatting 100 000 reads in
-    one place costs ~0.1 s, more than eight MI355X need to classify them.
+    one place costs ~0.1 s, more than eight MI355X need to classify them.  One node: all ranks must see ``directory`` as the same
+    file system (the job shards the reads over the GPUs of ONE node; a shared file system extends it to several).
     -> totals over all ranks: dict(reads, samples, reads_with_hp, hp_chunks, bytes) on every rank."""
     import os
     import torch.distributed as dist
