@@ -175,6 +175,31 @@ def test_config4_bf16_packed_varlen(ckpt_weights):
     assert worst <= 1e-2
 
 
+def test_config4_at_scale_is_invariant_to_the_packing(ckpt_weights):
+    """BASELINE configs[3] at a size the oracle cannot follow (2 000 reads, 9.3 M samples, bf16): windows are independent,
+    so which reads share a launch must not matter.  The same reads through 4 096-window buckets, through the CLI's
+    131 072-window launches (where the fused residual stack runs one chunk per tile and the biGRU kernels walk several
+    tiles per wave) and read by read give bit-identical probabilities and identical spans; read lengths come back exact."""
+    from catfish_amd import batching
+    from catfish_amd.engine import HipEngine
+    rng = np.random.default_rng(2)
+    lens = np.rint(np.exp(rng.uniform(np.log(512), np.log(16384), size=2000))).astype(int).tolist()
+    dacs = [np.clip(np.rint(rng.normal(500, 60, size=n)), 0, 2047).astype(np.int16) for n in lens]
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=131072, precision="bf16")
+    try:
+        small, p_small = batching.infer_reads_dac(eng, dacs, max_windows=4096, return_probs=True)
+        big, p_big = batching.infer_reads_dac(eng, dacs, max_windows=131072, return_probs=True)
+        assert [n for _s, n in small] == lens == [n for _s, n in big]
+        assert small == big
+        assert all(np.array_equal(a, b) for a, b in zip(p_small, p_big))
+        for i in (0, 7, 1999, int(np.argmax(lens)), int(np.argmin(lens))):
+            one, p_one = batching.infer_reads_dac(eng, [dacs[i]], max_windows=4096, return_probs=True)
+            assert one[0] == big[i] and np.array_equal(p_one[0], p_big[i])
+        assert all(np.isfinite(p).all() and p.min() >= 0 and p.max() <= 1 for p in p_big)
+    finally:
+        eng.close()
+
+
 def test_full_size_properties(model):
     """BASELINE size (256 reads x 118 windows): window-permutation equivariance, batch-split
     invariance and run-to-run determinism -- size-independent properties of independent windows."""
