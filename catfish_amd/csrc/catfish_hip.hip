@@ -725,6 +725,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x_
 
 #include "gru_bf16.hpp"
 #include "gru_bf16_pipe.hpp"
+#include "gru_bf16x3_pipe.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 3: head -- logits = p_fw + p_bw + b, probs = sigmoid (rnn_class.py:84,179-181),
@@ -1320,6 +1321,10 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_bf16_pipe_kernel<32, true>, gb_pack_bytes(32, 1));
         optin((const void*)gru_bf16_pipe_kernel<128, false>, gb_pack_bytes(128, 1));
         optin((const void*)gru_bf16_pipe_kernel<128, true>, gb_pack_bytes(128, 1));
+        optin((const void*)gru_bf16x3_pipe_kernel<32, false>, gb_pack_bytes(32, 2));
+        optin((const void*)gru_bf16x3_pipe_kernel<32, true>, gb_pack_bytes(32, 2));
+        optin((const void*)gru_bf16x3_pipe_kernel<128, false>, gb_pack_bytes(128, 2));
+        optin((const void*)gru_bf16x3_pipe_kernel<128, true>, gb_pack_bytes(128, 2));
         optin((const void*)gru_layer_bf16_kernel<32, false, 2>, gb_pack_bytes(32, 2));
         optin((const void*)gru_layer_bf16_kernel<32, true, 2>, gb_pack_bytes(32, 2));
         optin((const void*)gru_layer_bf16_kernel<128, false, 2>, gb_pack_bytes(128, 2));
@@ -1415,10 +1420,21 @@ static int launch_gru_bf16(cf_model* m, const char* wpack, const float* X, float
     size_t pi = 0;
     int rc = prof_begin(m, slot, s, &pi);
     if (rc != CF_OK) return rc;
-    static const int pipe_env = cf_knob("CATFISH_BF16_PIPE") ? atoi(cf_knob("CATFISH_BF16_PIPE")) : 1;   // A/B knob for tools/
+    const int pipe_env = cf_knob("CATFISH_BF16_PIPE") ? atoi(cf_knob("CATFISH_BF16_PIPE")) : 1;   // A/B knob for tools/ and tests, read per launch
     if constexpr (NP == 1) {
         if (pipe_env) {      // plain bf16: the software-pipelined kernel (vector work issued behind every MFMA)
             hipLaunchKernelGGL((gru_bf16_pipe_kernel<CIN, LAST>), dim3(gx, 2), dim3(waves * 64), lds_bytes, s, wpack,
+                               reinterpret_cast<const bf16x8*>(X), reinterpret_cast<bf16x8*>(Y), P, n_tiles32);
+            HIP_TRY(hipGetLastError());
+            return prof_end(m, s, pi);
+        }
+    }
+    if constexpr (NP == 2) {
+        if (pipe_env) {      // bf16x3: the one-wave-per-SIMD pipelined kernel (512 registers, four waves per workgroup)
+            const int w4 = std::min(waves, 4);
+            const int g4 = (n_tiles32 + w4 - 1) / w4;
+            const int per4 = wgs_env > 0 ? wgs_env : std::max(1, m->n_cu / 2);       // one workgroup per CU whatever its LDS
+            hipLaunchKernelGGL((gru_bf16x3_pipe_kernel<CIN, LAST>), dim3(std::min(g4, per4), 2), dim3(w4 * 64), lds_bytes, s, wpack,
                                reinterpret_cast<const bf16x8*>(X), reinterpret_cast<bf16x8*>(Y), P, n_tiles32);
             HIP_TRY(hipGetLastError());
             return prof_end(m, s, pi);

@@ -483,3 +483,39 @@ def test_other_depths(n_layers, n_layers_res, precision):
             eng.close()
         want = oracle.forward(x, w, np.float64, n_layers=n_layers, n_layers_res=n_layers_res)
         assert np.abs(got - want).max() < 1e-4, (n, np.abs(got - want).max())
+
+
+def test_bf16x3_pipelined_kernel_agrees_with_unpipelined(ckpt_weights, monkeypatch):
+    """gru_bf16x3_pipe_kernel (one wave per SIMD, every vector instruction placed in an MFMA gap by a compile-time schedule)
+    against gru_layer_bf16_kernel<.,.,2> (CATFISH_BF16_PIPE=0 behind the debug switch).  Same products in the same order per
+    accumulator, same activation arithmetic -- but not the same bits: the round-1 kernel leaves the lo part of r*h to the
+    compiler, which contracts most (not all) of its `r*h - hi` into an fma, while the pipelined kernel pins every operation.
+    That moves single bf16 lo parts by one ulp (2^-17 of the value).  So: the two agree to 4e-6 in probability at every call
+    size -- one ragged tile, a few tiles, fewer tiles than waves, the benchmark's launch +- a ragged tile, a multi-round
+    launch (a lost or stale lo fragment anywhere shows as >= 1e-4) -- and each stays inside the 1e-4 gate of the fp64 oracle."""
+    from catfish_amd.engine import HipEngine
+    monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=70000, precision="bf16x3")
+    try:
+        for n in (1, 33, 118, 1000, 4097, 30208 + 7, 65536 + 31):
+            x = np.random.default_rng(n).normal(0, 1.4, size=(n, 35)).astype(np.float32)
+            monkeypatch.delenv("CATFISH_BF16_PIPE", raising=False)
+            new, new_logits = eng.infer_host(x, return_logits=True)
+            monkeypatch.setenv("CATFISH_BF16_PIPE", "0")
+            old, old_logits = eng.infer_host(x, return_logits=True)
+            assert np.isfinite(new).all() and np.isfinite(new_logits).all(), n
+            assert np.abs(new - old).max() < 4e-6, (n, np.abs(new - old).max())
+            m = min(n, 300)
+            want = oracle.forward(x[-m:], ckpt_weights, np.float64)
+            assert np.abs(new[-m * 35:] - want).max() < TOL and np.abs(old[-m * 35:] - want).max() < TOL, n
+            assert np.abs(1.0 / (1.0 + np.exp(-new_logits.astype(np.float64))) - new).max() < 1e-6
+    finally:
+        eng.close()
+    # another geometry of the stack around it: random weights, the oracle as the judge
+    w = oracle.random_weights(seed=77)
+    eng = HipEngine(w, device=0, max_windows_per_pass=4096, precision="bf16x3")
+    try:
+        x = np.random.default_rng(8).normal(0, 1.3, size=(777, 35)).astype(np.float32)
+        assert np.abs(eng.infer_host(x) - oracle.forward(x, w, np.float64)).max() < TOL
+    finally:
+        eng.close()
