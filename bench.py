@@ -117,7 +117,7 @@ def mid_roofline(kern, precision, samples_per_launch, traffic=None, traffic_sour
         traffic = t.get("gru_layer_mid_bytes_per_launch") if t else None
     achieved = FLOP_PER_SAMPLE_GRU128 * samples_per_launch / (ms / n * 1e-3) / 1e12
     peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    kname = {"fp32": "gru_layer_kernel<128,false>", "bf16x3": "gru_layer_bf16_kernel<128,false,2>",
+    kname = {"fp32": "gru_layer_kernel<128,false>", "bf16x3": "gru_bf16x3_pipe_kernel<128,false>",
              "bf16": "gru_bf16_pipe_kernel<128,false>"}[precision]
     launch_s = ms / n * 1e-3
     roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -138,10 +138,19 @@ def nearer_roof(roof, precision, samples, seconds):
     if roof.get("traffic"):
         hbm_view["traffic_rate"] = roof["traffic"] / seconds / 1e9
         hbm_view["traffic_rate_frac"] = hbm_view["traffic_rate"] / PEAK_HBM_GBS
-    # bf16: the matrix roof is 16x further away than in fp32 while the slabs only halve -- whichever fraction is larger binds;
-    # the measured traffic (1.5x the algorithmic bytes: each direction reads the whole input slab) decides a near tie
-    nearest = max(hbm_view["frac"], hbm_view.get("traffic_rate_frac", 0.0))
-    if nearest > roof["frac"]:
+    # Which roof binds is decided on the quantities the line reports: algorithmic bytes against HBM, and against the matrix pipe
+    # the FLOPs the kernel ISSUES -- bf16x3 spends three bf16 MFMAs per product (a_hi w_hi + a_lo w_hi + a_hi w_lo), so its
+    # pipe does 3x the algorithmic FLOPs.  (bf16: the matrix roof is 16x further away than in fp32 while the slabs only halve.)
+    issue_factor = 3.0 if precision == "bf16x3" else 1.0
+    pipe_frac = roof["frac"] * issue_factor
+    if issue_factor != 1.0:
+        # the dense peak assumes 2.4 GHz; under bf16 MFMA load on random data the chip holds ~1.5 GHz (tools/exp_x3_stamps.py), and
+        # MI355X_MICROARCH.md ('DVFS give-back' item 1) quotes 1,247 TFLOP/s for a tuned 256^2 GEMM on random operands
+        roof["matrix_pipe_issued"] = {"achieved": roof["achieved"] * issue_factor, "peak": roof["peak"], "unit": "TFLOP/s",
+                                      "frac": pipe_frac, "mfma_per_product": int(issue_factor),
+                                      "tuned_gemm_on_random_data_tflops": 1247.0,
+                                      "frac_of_that": roof["achieved"] * issue_factor / 1247.0}
+    if hbm_view["frac"] > pipe_frac:
         mfma_view = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
         roof.update(bound="hbm", achieved=hbm, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm / PEAK_HBM_GBS, mfma_view=mfma_view,
                     hbm_detail=hbm_view)

@@ -158,6 +158,20 @@ class ChunkTable(object):
 DOCUMENTS = ("hp_positions.json", "nonhp_positions.json")
 
 
+def _pwrite_all(fd, data, offset):
+    """``os.pwrite`` until every byte is on its way: one call may write less than it was given (a signal, a full pipe of the
+    file system's, a quota edge); an unlooped call would leave a hole of NULs in the document and nobody would notice."""
+    import errno
+    import os
+    view = memoryview(data)
+    done = 0
+    while done < len(view):
+        n = os.pwrite(fd, view[done:], offset + done)
+        if n <= 0:
+            raise OSError(errno.EIO, "pwrite wrote nothing at offset %d" % (offset + done))
+        done += n
+
+
 def write_json_documents(directory, table, names, group=None):
     """Write the two chunk-coordinate documents of a (sharded) run, every rank its own part of them IN PARALLEL.
 
@@ -169,9 +183,16 @@ def write_json_documents(directory, table, names, group=None):
     ``hp_dict`` / ``nonhp_dict``), and rank 0 does nothing that grows with the number of ranks: formatting 100 000 reads in
     one place costs ~0.1 s, more than eight MI355X need to classify them.  One node: all ranks must see ``directory`` as the same
     file system (the job shards the reads over the GPUs of ONE node; a shared file system extends it to several).
+
+    Failure: the documents are built under ``<name>.part`` and renamed by rank 0 only after EVERY rank has reported its
+    writes complete; creating, writing and publishing each end in ``sharding.agree_or_raise`` (which doubles as the barrier
+    between the stages), so an I/O error on one rank -- EACCES, ENOSPC, a short write that will not complete -- raises on
+    all of them at once, naming the rank, and leaves neither a document nor a ``.part`` behind (an exception aborts the run,
+    as in the reference: catfish/split_f5.py:23-32).
     -> totals over all ranks: dict(reads, samples, reads_with_hp, hp_chunks, bytes) on every rank."""
     import os
     import torch.distributed as dist
+    from .sharding import agree_or_raise
     texts = table.json_members(names)
     mine = (len(texts[0]), len(texts[1]), len(table), int(table.lengths.sum()), int(table.has_hp.sum()), int(table.hp_bounds[-1]))
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -181,8 +202,8 @@ def write_json_documents(directory, table, names, group=None):
         dist.all_gather_object(every, mine, group=group)
     else:
         rank, every = 0, [mine]
-    sizes = []
-    for d, name in enumerate(DOCUMENTS):
+    layout = []                                             # per document: (my offset, my separator, total size)
+    for d in range(len(DOCUMENTS)):
         pos, seen, my_off, my_sep = 1, False, 0, b""
         for r, counts in enumerate(every):
             n = counts[d]
@@ -191,26 +212,56 @@ def write_json_documents(directory, table, names, group=None):
                 my_off, my_sep = pos, sep
             pos += len(sep) + n
             seen = seen or n > 0
-        total = pos + 1
-        sizes.append(total)
-        path = os.path.join(directory, name)
-        if rank == 0:
+        layout.append((my_off, my_sep, pos + 1))
+    finals = [os.path.join(directory, name) for name in DOCUMENTS]
+    parts = [path + ".part" for path in finals]
+
+    def stage(what, work, leftovers):
+        """Run this rank's share of a stage, then let every rank learn how it went; on any failure rank 0 removes what exists."""
+        error = None
+        try:
+            work()
+        except OSError as exc:
+            error = exc
+        try:
+            agree_or_raise(error, what, group=group)
+        except Exception:
+            if rank == 0:
+                for path in leftovers:
+                    try:
+                        os.unlink(path)
+                    except OSError:
+                        pass
+            raise
+
+    def create():
+        if rank != 0:
+            return
+        for path, (_off, _sep, total) in zip(parts, layout):
             fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
             try:
                 os.ftruncate(fd, total)
-                os.pwrite(fd, b"{", 0)
-                os.pwrite(fd, b"}", total - 1)
+                _pwrite_all(fd, b"{", 0)
+                _pwrite_all(fd, b"}", total - 1)
             finally:
                 os.close(fd)
-        if distributed:
-            dist.barrier(group=group)                       # the file exists at its final size before anyone writes into it
-        if texts[d]:
-            fd = os.open(path, os.O_WRONLY)
-            try:
-                os.pwrite(fd, my_sep + texts[d], my_off)
-            finally:
-                os.close(fd)
-    if distributed:
-        dist.barrier(group=group)                           # complete documents when any rank returns
+
+    def write():
+        for d, path in enumerate(parts):
+            if texts[d]:
+                fd = os.open(path, os.O_WRONLY)
+                try:
+                    _pwrite_all(fd, layout[d][1] + texts[d], layout[d][0])
+                finally:
+                    os.close(fd)
+
+    def publish():
+        if rank == 0:
+            for part, final in zip(parts, finals):
+                os.replace(part, final)
+
+    stage("creating the chunk documents", create, parts)        # the files exist at their final size before anyone writes into them
+    stage("writing the chunk documents", write, parts)
+    stage("publishing the chunk documents", publish, parts + finals)   # complete documents under their names when any rank returns
     return {"reads": sum(c[2] for c in every), "samples": sum(c[3] for c in every), "reads_with_hp": sum(c[4] for c in every),
-            "hp_chunks": sum(c[5] for c in every), "bytes": sizes}
+            "hp_chunks": sum(c[5] for c in every), "bytes": [total for _off, _sep, total in layout]}

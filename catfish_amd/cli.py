@@ -13,6 +13,7 @@ is not installed the chunk coordinates are written as JSON next to the would-be 
 from __future__ import annotations
 
 import datetime
+import hashlib
 import json
 import os
 
@@ -104,7 +105,7 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
         input_dir = os.path.abspath(input_dir)
         network_path = os.path.abspath(network_path)
-        model = input_files = file_sizes = max_windows = None
+        model = input_files = file_sizes = max_windows = listing_digest = None
         t1 = datetime.datetime.now()
         setup_error = None
         try:
@@ -115,6 +116,9 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
                 listing = sorted((entry.name, entry.stat().st_size) for entry in scan)
             input_files = [name for name, _size in listing]
             file_sizes = [size for _name, size in listing]
+            # every rank cuts its block out of ITS OWN listing: a file still being copied in, or stale NFS attributes on one
+            # rank, would make the blocks overlap or leave gaps with plausible totals -- so the ranks compare a digest of it
+            listing_digest = hashlib.sha1(repr(listing).encode()).hexdigest()
             # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
             # tail instead of 8 % and the three layers go out as one dynamically scheduled launch.
             max_windows = 131072 if len(input_files) > 400 * world else 32768
@@ -123,7 +127,8 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
                                                 max_windows_per_pass=max_windows, precision=precision)
         except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
             setup_error = exc
-        sharding.agree_or_raise(setup_error, "set-up (output directories, network)", group=host_group)
+        sharding.agree_or_raise(setup_error, "set-up (output directories, network, listing of the input directory)", group=host_group,
+                                token=listing_digest)
         timings["setup_s"] = (datetime.datetime.now() - t1).total_seconds()
         if rank == 0:
             print("Loaded model in {}".format(datetime.datetime.now() - t1))

@@ -99,23 +99,30 @@ def init_host_group(timeout_s=None):
     return True
 
 
-def agree_or_raise(error, stage, group=None):
+def agree_or_raise(error, stage, group=None, token=None):
     """Every rank reports how its ``stage`` went (``error`` = the exception it caught, or None) and all of them learn the
     outcome: a rank that failed re-raises its own exception, the others raise a RuntimeError naming it.  One small
     all-gather; call it after any per-rank step that can fail BEFORE the data path (creating directories, loading the
-    network, opening the device), so that no rank walks into a later collective its peers will never reach."""
+    network, opening the device), so that no rank walks into a later collective its peers will never reach.
+
+    ``token`` (optional, any small picklable value) rides along: when no rank failed but the ranks' tokens differ, all of them
+    raise -- for facts every rank derives on its own and all must agree on (the listing of the input directory)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         if error is not None:
             raise error
         return
     said = [None] * dist.get_world_size()
-    dist.all_gather_object(said, None if error is None else "%s: %s" % (type(error).__name__, error), group=group)
+    dist.all_gather_object(said, (None if error is None else "%s: %s" % (type(error).__name__, error), token), group=group)
     if error is not None:
         raise error
-    bad = ["rank %d: %s" % (r, t) for r, t in enumerate(said) if t is not None]
+    bad = ["rank %d: %s" % (r, t) for r, (t, _tok) in enumerate(said) if t is not None]
     if bad:
         raise RuntimeError("%s failed on %s" % (stage, "; ".join(bad)))
+    differing = [r for r, (_t, tok) in enumerate(said) if tok != said[0][1]]
+    if differing:
+        raise RuntimeError("%s: rank(s) %s disagree with rank 0 (%r against %r)" % (
+            stage, ", ".join(str(r) for r in differing), said[differing[0]][1], said[0][1]))
 
 
 def host_gather_group():
