@@ -144,10 +144,12 @@ def test_packed_variable_length_reads_match_per_read_oracle(model, ckpt_weights)
 def test_config4_bf16_packed_varlen(ckpt_weights):
     """BASELINE configs[3] as stated: variable-length reads 512..16384 (log-uniform, seed 2) as raw DAC squiggles, in
     length-bucketed PACKED launches, bf16 biGRU arithmetic -- through batching.infer_reads_dac (device normalisation,
-    forward pass, device post-processing).  Judged like SURVEY 8d says: label match rate against the fp32 oracle
-    (>= 0.998 over all samples) and max |dp| <= 1e-2 per read; edge lengths 512, 16384, 35k and 35k + 1 included."""
+    forward pass, device post-processing).  Judged like SURVEY 8d says, by the constants of oracle/tolerances.py that the
+    bench's config4 leg uses too: label match rate against the fp32 oracle over all samples and per read, and the loose
+    bound on max |dp|; edge lengths 512, 16384, 35k and 35k + 1 included."""
     from catfish_amd import batching
     from catfish_amd.engine import HipEngine
+    from oracle import tolerances as tol
     rng = np.random.default_rng(2)
     lens = np.exp(rng.uniform(np.log(512), np.log(16384), size=22)).astype(int).tolist() + [512, 16384, 35 * 40, 35 * 40 + 1, 35 * 300]
     dacs = [oracle.synthetic_dac(1, n, seed=2000 + i)[0] for i, n in enumerate(lens)]
@@ -166,13 +168,13 @@ def test_config4_bf16_packed_varlen(ckpt_weights):
         worst = max(worst, float(np.abs(p - want).max()))
         m = (p >= 0.5) == (want >= 0.5)
         n_match += int(m.sum()); n_tot += n
-        assert m.mean() >= 0.99, (n, m.mean())
+        assert m.mean() >= tol.CONFIG4_MIN_LABEL_MATCH_PER_READ, (n, m.mean())
         # spans are what the tool emits: they come from the bf16 labels through correct_short + hp_in_pred
         lab = oracle.correct_short(oracle.class_from_threshold(p))
         assert spans == (oracle.hp_in_pred(lab) if lab.any() else [])
     print("config 4: label match %.5f over %d samples, max |dp| %.2e" % (n_match / n_tot, n_tot, worst))
-    assert n_match / n_tot >= 0.998
-    assert worst <= 1e-2
+    assert n_match / n_tot >= tol.CONFIG4_MIN_LABEL_MATCH
+    assert worst <= tol.CONFIG4_MAX_ABS_DP
 
 
 def test_config4_at_scale_is_invariant_to_the_packing(ckpt_weights):

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktrace -o kt -- pyt
 python3 - "$COMMIT" "$PREC" <<'PY'
 import csv, glob, json, sys, time, collections
 commit, prec = sys.argv[1], sys.argv[2]
-pat = "gru_layer_kernel<128, false>" if prec == "fp32" else ("gru_bf16_pipe_kernel<128, false>" if prec == "bf16" else "gru_layer_bf16_kernel<128, false, 2>")
+pat = "gru_layer_kernel<128, false>" if prec == "fp32" else ("gru_bf16_pipe_kernel<128, false>" if prec == "bf16" else "gru_bf16x3_pipe_kernel<128, false>")
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
