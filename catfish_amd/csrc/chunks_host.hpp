@@ -27,13 +27,15 @@ static inline void center(Span& s, int64_t len_read, int64_t chunk) {
 
 }  // namespace cf_chunks
 
-extern "C" int cf_chunks_from_spans(const int64_t* span_bounds, const int64_t* span_start, const int64_t* span_end,
-                                    const int64_t* lengths, int64_t n_reads, int64_t chunk_size,
-                                    int64_t* hp_bounds, int64_t* hp_start, int64_t* hp_end, int64_t hp_capacity,
-                                    int64_t* nonhp_bounds, int64_t* nonhp_start, int64_t* nonhp_end, int64_t nonhp_capacity) {
+static int chunks_from_spans(const int64_t* span_bounds, const int64_t* span_start, const int64_t* span_end,
+                             const int64_t* lengths, int64_t n_reads, int64_t chunk_size,
+                             int64_t* hp_bounds, int64_t* hp_start, int64_t* hp_end, int64_t hp_capacity,
+                             int64_t* nonhp_bounds, int64_t* nonhp_start, int64_t* nonhp_end, int64_t nonhp_capacity) {
     using cf_chunks::Span;
-    if (n_reads < 0) return fail(CF_ERR_INVALID, "cf_chunks_from_spans: negative n_reads");
+    if (n_reads < 0 || hp_capacity < 0 || nonhp_capacity < 0) return fail(CF_ERR_INVALID, "cf_chunks_from_spans: negative size");
     if (!span_bounds || !lengths || !hp_bounds || !nonhp_bounds) return fail(CF_ERR_INVALID, "cf_chunks_from_spans: null table");
+    if ((hp_capacity > 0 && (!hp_start || !hp_end)) || (nonhp_capacity > 0 && (!nonhp_start || !nonhp_end)))
+        return fail(CF_ERR_INVALID, "cf_chunks_from_spans: null output table");
     const int64_t n_spans = span_bounds[n_reads] - span_bounds[0];
     if (n_spans < 0 || (n_spans > 0 && (!span_start || !span_end))) return fail(CF_ERR_INVALID, "cf_chunks_from_spans: bad span table");
     std::vector<Span> work;
@@ -77,6 +79,18 @@ extern "C" int cf_chunks_from_spans(const int64_t* span_bounds, const int64_t* s
     return CF_OK;
 }
 
+extern "C" int cf_chunks_from_spans(const int64_t* span_bounds, const int64_t* span_start, const int64_t* span_end,
+                                    const int64_t* lengths, int64_t n_reads, int64_t chunk_size,
+                                    int64_t* hp_bounds, int64_t* hp_start, int64_t* hp_end, int64_t hp_capacity,
+                                    int64_t* nonhp_bounds, int64_t* nonhp_start, int64_t* nonhp_end, int64_t nonhp_capacity) {
+    try {       // (the working copies are std::vectors: no bad_alloc across the C ABI)
+        return chunks_from_spans(span_bounds, span_start, span_end, lengths, n_reads, chunk_size, hp_bounds, hp_start, hp_end, hp_capacity,
+                                 nonhp_bounds, nonhp_start, nonhp_end, nonhp_capacity);
+    } catch (const std::bad_alloc&) {
+        return fail(CF_ERR_NOMEM, "cf_chunks_from_spans: out of host memory");
+    }
+}
+
 // JSON members `"name": [[a, b], [c, d]]`, joined by ", " (what json.dump writes between the braces of a dict of lists of
 // pairs, default separators), for the reads that own at least one row of the table (whole_read given: for every read, `[]`
 // when it owns none -- the reference's nonhp_dict has an entry per read, its hp_dict only for reads with homopolymers).
@@ -86,7 +100,8 @@ extern "C" int cf_chunks_from_spans(const int64_t* span_bounds, const int64_t* s
 extern "C" int64_t cf_chunks_json(const char* keys, const int64_t* key_bounds, int64_t n_reads, const int64_t* bounds,
                                   const int64_t* start, const int64_t* end, const uint8_t* whole_read, char* out,
                                   int64_t capacity) {
-    if (n_reads < 0 || !key_bounds || !bounds || !out) return fail(CF_ERR_INVALID, "cf_chunks_json: bad arguments");
+    if (n_reads < 0 || capacity < 0 || !key_bounds || !bounds || !out || (n_reads > 0 && !keys))
+        return fail(CF_ERR_INVALID, "cf_chunks_json: bad arguments");
     int64_t w = 0;
     auto put_int = [&](int64_t v) {
         char tmp[24];
@@ -101,6 +116,7 @@ extern "C" int64_t cf_chunks_json(const char* keys, const int64_t* key_bounds, i
         const int64_t lo = bounds[r], hi = bounds[r + 1];
         if (hi <= lo && !whole_read) continue;
         const int64_t klen = key_bounds[r + 1] - key_bounds[r];
+        if (klen < 0 || (hi > lo && (!start || !end))) return fail(CF_ERR_INVALID, "cf_chunks_json: bad tables");
         if (w + klen + 8 + (hi - lo) * 48 + 32 > capacity) return fail(CF_ERR_INVALID, "cf_chunks_json: capacity too small");
         if (!first) { out[w++] = ','; out[w++] = ' '; }
         first = false;

@@ -8,69 +8,113 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <thread>
+#include <new>
+#include <stdexcept>
 
 namespace cf_loader {
 
 struct Item {
-    std::vector<unsigned char> bytes;    // whole file
+    std::vector<unsigned char> bytes;    // whole file (allocated only once the header has vouched for its size)
     size_t data_off = 0;
     int64_t count = -1;                  // samples; < 0: not a plain int16 vector (or unreadable)
 };
 
-// the byte-level header check of catfish_amd/infer.py::_read_npy_int16: magic, version 1 or 2, '<i2', C order, one dimension,
-// and the file exactly as long as header + data
-static bool parse(Item& it) {
-    const std::vector<unsigned char>& b = it.bytes;
-    if (b.size() < 12 || memcmp(b.data(), "\x93NUMPY", 6) != 0 || (b[6] != 1 && b[6] != 2)) return false;
+static const size_t HEAD_FIRST = 4096;          // bytes read before the header has been judged
+static const size_t HEAD_MAX = 1u << 20;        // no numpy header of a one-dimensional array is anywhere near this long
+
+// the byte-level header check of catfish_amd/infer.py::_read_npy_int16 on the first `have` bytes of a file of `file_size`
+// bytes: magic, version 1 or 2, '<i2', C order, one dimension, and the file exactly as long as header + data.
+// -> 1 ok (data_off, count set), 0 not such a file, -1 the header is longer than `have` (need_head set: read that much and call again)
+static int parse(const unsigned char* b, size_t have, size_t file_size, size_t& data_off, int64_t& count, size_t& need_head) {
+    if (file_size < 12 || have < 12 || memcmp(b, "\x93NUMPY", 6) != 0 || (b[6] != 1 && b[6] != 2)) return 0;
     size_t hlen, off;
     if (b[6] == 1) { hlen = (size_t)b[8] | ((size_t)b[9] << 8); off = 10; }
     else { hlen = (size_t)b[8] | ((size_t)b[9] << 8) | ((size_t)b[10] << 16) | ((size_t)b[11] << 24); off = 12; }
-    if (off + hlen > b.size()) return false;
-    const std::string header(reinterpret_cast<const char*>(b.data() + off), hlen);
-    if (header.find("'descr': '<i2'") == std::string::npos || header.find("'fortran_order': False") == std::string::npos) return false;
+    if (hlen > HEAD_MAX || off + hlen > file_size) return 0;
+    if (off + hlen > have) { need_head = off + hlen; return -1; }
+    const std::string header(reinterpret_cast<const char*>(b + off), hlen);
+    if (header.find("'descr': '<i2'") == std::string::npos || header.find("'fortran_order': False") == std::string::npos) return 0;
     const size_t a = header.find("'shape': (");
-    if (a == std::string::npos) return false;
+    if (a == std::string::npos) return 0;
     const size_t close = header.find(')', a);
-    if (close == std::string::npos) return false;
+    if (close == std::string::npos) return 0;
     // exactly one dimension: digits, optional blanks, one comma
     size_t p = a + 10;
     while (p < close && header[p] == ' ') ++p;
     int64_t n = 0;
     size_t digits = 0;
-    while (p < close && header[p] >= '0' && header[p] <= '9') { n = n * 10 + (header[p] - '0'); ++p; ++digits; if (digits > 15) return false; }
-    if (digits == 0) return false;
+    while (p < close && header[p] >= '0' && header[p] <= '9') { n = n * 10 + (header[p] - '0'); ++p; ++digits; if (digits > 15) return 0; }
+    if (digits == 0) return 0;
     int commas = 0;
     for (; p < close; ++p) {
         if (header[p] == ',') ++commas;
-        else if (header[p] != ' ') return false;
+        else if (header[p] != ' ') return 0;
     }
-    if (commas > 1) return false;
-    if (b.size() != off + hlen + 2 * (size_t)n) return false;
-    it.data_off = off + hlen;
-    it.count = n;
+    if (commas > 1) return 0;
+    if (file_size != off + hlen + 2 * (size_t)n) return 0;
+    data_off = off + hlen;
+    count = n;
+    return 1;
+}
+
+static bool read_exact(int fd, unsigned char* dst, size_t n, size_t at) {
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t r = pread(fd, dst + got, n - got, (off_t)(at + got));
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
     return true;
 }
 
+// Header first: a directory, a FAST5, an .npz or a multi-gigabyte file of another kind is turned away after at most 4 KiB (its
+// header length, if it claims to be numpy) -- only a file whose header matches its size is read whole.
 static bool slurp(const char* path, Item& it) {
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return false;
     struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size < 0) { close(fd); return false; }
-    it.bytes.resize((size_t)st.st_size);
-    size_t got = 0;
-    while (got < it.bytes.size()) {
-        const ssize_t r = pread(fd, it.bytes.data() + got, it.bytes.size() - got, (off_t)got);
-        if (r <= 0) break;
-        got += (size_t)r;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 12;
+    if (ok) {
+        const size_t size = (size_t)st.st_size;
+        unsigned char first[HEAD_FIRST];
+        size_t have = std::min(size, HEAD_FIRST), need = 0;
+        ok = read_exact(fd, first, have, 0);
+        int verdict = ok ? parse(first, have, size, it.data_off, it.count, need) : 0;
+        if (verdict < 0) {                                // a header beyond the first 4 KiB (never seen; bounded by HEAD_MAX)
+            std::vector<unsigned char> head(need);
+            ok = read_exact(fd, head.data(), need, 0);
+            verdict = ok ? parse(head.data(), need, size, it.data_off, it.count, need) : 0;
+        }
+        ok = ok && verdict == 1;
+        if (ok) {
+            it.bytes.resize(size);
+            if (have == HEAD_FIRST || size == have) memcpy(it.bytes.data(), first, have);      // (else the long-header case: read anew)
+            else have = 0;
+            ok = read_exact(fd, it.bytes.data() + have, size - have, have);
+        }
     }
     close(fd);
-    return got == it.bytes.size();
+    if (!ok) it.count = -1;
+    return ok;
+}
+
+// body(t) on nt host threads; a thread that cannot be started (std::system_error) must not leave joinable ones behind
+template <class F>
+static void run_pool(int nt, F body) {
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 0; t < nt; ++t) pool.emplace_back(body, t);
+    } catch (...) {
+        for (std::thread& th : pool) th.join();
+        throw;
+    }
+    for (std::thread& th : pool) th.join();
 }
 
 }  // namespace cf_loader
 
-extern "C" int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
-                                 int64_t* lengths, int64_t* total, int32_t n_threads) {
+static int load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
+                          int64_t* lengths, int64_t* total, int32_t n_threads) {
     if (n_files < 0 || capacity < 0) return fail(CF_ERR_INVALID, "cf_load_npy_int16: negative size");
     if (total) *total = 0;
     if (n_files == 0) return CF_OK;
@@ -78,20 +122,17 @@ extern "C" int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, 
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 4, std::min<int64_t>(n_files, 64)));
     std::vector<cf_loader::Item> items((size_t)n_files);
     std::vector<int64_t> bad((size_t)nt, -1);                    // first offending file per thread
-    {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t)
-            pool.emplace_back([&, t]() {
-                for (int64_t i = t; i < n_files; i += nt) {      // interleaved: neighbouring files are neighbours on disk
-                    cf_loader::Item& it = items[(size_t)i];
-                    if (!cf_loader::slurp(paths + path_bounds[i], it) || !cf_loader::parse(it)) {
-                        it.count = -1;
-                        if (bad[(size_t)t] < 0) bad[(size_t)t] = i;
-                    }
-                }
-            });
-        for (std::thread& th : pool) th.join();
-    }
+    cf_loader::run_pool(nt, [&](int t) {
+        for (int64_t i = t; i < n_files; i += nt) {              // interleaved: neighbouring files are neighbours on disk
+            cf_loader::Item& it = items[(size_t)i];
+            bool ok = false;
+            try { ok = cf_loader::slurp(paths + path_bounds[i], it); } catch (...) { ok = false; }    // (bad_alloc: a thread may not throw)
+            if (!ok) {
+                it.count = -1;
+                if (bad[(size_t)t] < 0) bad[(size_t)t] = i;
+            }
+        }
+    });
     int64_t first_bad = -1;
     for (int64_t b : bad)
         if (b >= 0 && (first_bad < 0 || b < first_bad)) first_bad = b;
@@ -105,16 +146,23 @@ extern "C" int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, 
     }
     if (total) *total = offs[(size_t)n_files];
     if (offs[(size_t)n_files] > capacity) return fail(CF_ERR_INVALID, "cf_load_npy_int16: the reads do not fit the buffer");
-    {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; ++t)
-            pool.emplace_back([&, t]() {
-                for (int64_t i = t; i < n_files; i += nt) {
-                    const cf_loader::Item& it = items[(size_t)i];
-                    memcpy(out + offs[(size_t)i], it.bytes.data() + it.data_off, 2 * (size_t)it.count);
-                }
-            });
-        for (std::thread& th : pool) th.join();
-    }
+    cf_loader::run_pool(nt, [&](int t) {
+        for (int64_t i = t; i < n_files; i += nt) {
+            const cf_loader::Item& it = items[(size_t)i];
+            if (it.count > 0) memcpy(out + offs[(size_t)i], it.bytes.data() + it.data_off, 2 * (size_t)it.count);
+        }
+    });
     return CF_OK;
+}
+
+// (no C++ exception may cross the C ABI: std::bad_alloc from the tables, std::system_error from std::thread)
+extern "C" int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
+                                 int64_t* lengths, int64_t* total, int32_t n_threads) {
+    try {
+        return load_npy_int16(paths, path_bounds, n_files, out, capacity, lengths, total, n_threads);
+    } catch (const std::bad_alloc&) {
+        return fail(CF_ERR_NOMEM, "cf_load_npy_int16: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(CF_ERR_INVALID, std::string("cf_load_npy_int16: ") + e.what());
+    }
 }

@@ -72,7 +72,7 @@ class ReadPipeline(object):
         this batch needs the general loader (a file of another kind, or reads that do not fit the staging buffer): nothing
         has been consumed then."""
         paths = [os.fsencode(p) for p in paths]
-        if not paths:
+        if not paths or not all(p.endswith(b".npy") for p in paths):      # infer.load_dac's own dispatch: only .npy takes this path
             return None
         slot = self._claim_slot()
         blob = b"\x00".join(paths) + b"\x00"
