@@ -1483,7 +1483,9 @@ static int run_pass(cf_model* m, cf_model::Slot& sl, const float* x, int64_t n_w
         // bf16: two tiles per wave (every LDS read of a weight fragment or bias vector feeds two tiles: the kernel is bound
         // by LDS bandwidth), two waves per SIMD; bf16x3: one tile per wave (twice the fragments), two waves per SIMD
         const int np = m->np > 1 ? 2 : 1;
-        const int tpw = cf_knob("CATFISH_RES_TPW") ? atoi(cf_knob("CATFISH_RES_TPW")) : 1;       // A/B knob for tools/
+        // A/B knob for tools/: two tiles per wave exist for one bf16 part only; any other value would launch a kernel that covers
+        // 1 / tpw of the tiles and leave the rest of the slab stale
+        const int tpw = (np == 1 && cf_knob("CATFISH_RES_TPW") && atoi(cf_knob("CATFISH_RES_TPW")) == 2) ? 2 : 1;
         const int groups = (n_tiles32 + tpw - 1) / tpw;
         const int slots = (np == 1 && tpw == 1 ? 4 * CF_RES_BF16_WAVES : 8) * m->n_cu;          // wave tasks resident at once on the whole chip
         // as many chunks as keep every task resident in ONE round (a second, mostly empty round costs a whole chunk's chain)
