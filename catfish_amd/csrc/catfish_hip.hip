@@ -1321,6 +1321,8 @@ extern "C" int cf_model_create(const cf_weights* w, const cf_hparams* hp, int de
         optin((const void*)gru_bf16_pipe_kernel<32, true>, gb_pack_bytes(32, 1));
         optin((const void*)gru_bf16_pipe_kernel<128, false>, gb_pack_bytes(128, 1));
         optin((const void*)gru_bf16_pipe_kernel<128, true>, gb_pack_bytes(128, 1));
+        optin((const void*)gru_xproj_lds_kernel<32>, gru_x_floats(32) * 4);
+        optin((const void*)gru_xproj_lds_kernel<128>, gru_x_floats(128) * 4);
         optin((const void*)gru_bf16x3_pipe_kernel<32, false>, gb_pack_bytes(32, 2));
         optin((const void*)gru_bf16x3_pipe_kernel<32, true>, gb_pack_bytes(32, 2));
         optin((const void*)gru_bf16x3_pipe_kernel<128, false>, gb_pack_bytes(128, 2));
@@ -1371,6 +1373,21 @@ static bool use_coop(const cf_model* m, int n_tiles) {
     return coop && !(CF_ABLATE & 4) && n_tiles <= m->n_cu;      // (the raw dense-partial buffer is sized for n_cu tiles)
 }
 
+// x projection of a small call on the CUs its recurrence leaves idle (gru_coop.hpp): weights through LDS, chunks sized to fill
+// the chip once; CATFISH_XPROJ_LDS=0 behind the debug switch selects round 2's kernel (fragments straight from L2), for A/B
+template <int CIN>
+static void launch_xproj(cf_model* m, const float* wpack, const float* X, int n_tiles, hipStream_t s) {
+    const int lds_env = cf_knob("CATFISH_XPROJ_LDS") ? atoi(cf_knob("CATFISH_XPROJ_LDS")) : 1;
+    if (lds_env) {
+        const int chunks = cf_xproj_plan(n_tiles, m->n_cu, CIN);
+        hipLaunchKernelGGL((gru_xproj_lds_kernel<CIN>), dim3(n_tiles * chunks, 2), dim3(256), gru_x_floats(CIN) * 4, s, wpack,
+                           reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(m->d_xp), n_tiles, chunks);
+    } else {
+        hipLaunchKernelGGL((gru_xproj_kernel<CIN>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack,
+                           reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
+    }
+}
+
 template <int CIN, bool LAST>
 static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y, float* P, int n_tiles, hipStream_t s, int slot) {
     if (use_coop(m, n_tiles)) {
@@ -1381,8 +1398,7 @@ static int launch_gru(cf_model* m, const float* wpack, const float* X, float* Y,
         const f32x4* xp = nullptr;
         if (CIN >= 32 && n_tiles <= m->xp_tiles) {        // few tiles: the x projection runs on the idle CUs first
             xp = reinterpret_cast<const f32x4*>(m->d_xp);
-            hipLaunchKernelGGL((gru_xproj_kernel<CIN>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(X),
-                               reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
+            launch_xproj<CIN>(m, wpack, X, n_tiles, s);
         }
         hipLaunchKernelGGL((gru_layer_coop_kernel<CIN, LAST>), dim3(gx, 2), dim3(256), (gru_pack_floats(CIN) + CF_COOP_XCH_FLOATS) * 4, s,
                            wpack, reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(Y), P, n_tiles, xp);
@@ -1876,15 +1892,11 @@ extern "C" int cf_gru_train_forward_dropout(cf_model* m, int32_t cin, const floa
         const bool hoist = n_tiles <= m->xp_tiles;
         const f32x4* xp = hoist ? reinterpret_cast<const f32x4*>(m->d_xp) : nullptr;
         if (cin == CF_C) {
-            if (hoist)
-                hipLaunchKernelGGL((gru_xproj_kernel<32>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
-                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
+            if (hoist) launch_xproj<32>(m, wpack, x_frag, n_tiles, s);
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gru_pack_floats(32) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
                                reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp, yd, drop);
         } else {
-            if (hoist)
-                hipLaunchKernelGGL((gru_xproj_kernel<128>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack, reinterpret_cast<const f32x4*>(x_frag),
-                                   reinterpret_cast<f32x4*>(m->d_xp), n_tiles, cf_xproj_chunks(n_tiles));
+            if (hoist) launch_xproj<128>(m, wpack, x_frag, n_tiles, s);
             hipLaunchKernelGGL((gru_train_fwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gru_pack_floats(128) + CF_COOP_XCH_FLOATS) * 4, s, wpack,
                                reinterpret_cast<const f32x4*>(x_frag), reinterpret_cast<f32x4*>(y_frag), reinterpret_cast<f32x4*>(stash), n_tiles, xp, yd, drop);
         }

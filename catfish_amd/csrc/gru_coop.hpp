@@ -227,6 +227,98 @@ __global__ __launch_bounds__(256) void gru_xproj_kernel(const float* __restrict_
     }
 }
 
+// The same x projection with the layer's x weights staged in LDS (round 4).  gru_xproj_kernel gives every wave its own copy of
+// its fragments straight from L2 -- 96 dword loads per lane, 24 KiB per wave -- and, for a tiny call, one workgroup per (tile,
+// step): a single read's 560 workgroups pull 54 MB through L2 and the launch lasts 23 us (Cin = 128), a quarter of the whole
+// call, for 2.6 us of MFMA work.  Here a workgroup copies the 96 KiB x region once with 16-byte loads, takes a CHUNK of steps
+// of one (tile, direction) and its four waves read their fragments (one dword each: wave W owns M-tiles {r[W], u[W], c[W]})
+// from LDS through a register ring.  Bias first, k ascending: the in-kernel x part's order, hence its bits.  The launcher sizes
+// the chunks so that the grid fills the chip once (cf_xproj_plan).
+template <int CIN>
+__global__ __launch_bounds__(256) void gru_xproj_lds_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
+                                                            f32x4* __restrict__ XP, int n_tiles, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KGX = CIN / 16;
+    constexpr int KSX = CIN / 4;
+    constexpr int PACK = gru_pack_floats(CIN);
+    constexpr int BIAS = gru_bias_off(CIN);
+    constexpr int XN4 = gru_x_floats(CIN) / 4;
+    constexpr int PF = 4;                                  // fragment prefetch depth (k-steps)
+    static_assert(KSX % PF == 0, "ring slots must not move across steps");
+    const int dir = blockIdx.y;
+    const int tile = blockIdx.x / chunks, chunk = blockIdx.x - tile * chunks;
+    const int lane = threadIdx.x & 63;
+    const int W = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* wp = wpack + (size_t)dir * PACK;
+    const int TL = (CF_T + chunks - 1) / chunks;
+    const int t_begin = chunk * TL, t_end = min(t_begin + TL, CF_T);
+    if (t_begin >= t_end) return;                          // (whole workgroup: the chunk count need not divide 35)
+    // this wave's inputs of the first step and its bias rows are on their way while the weights are staged
+    f32x4 xc[KGX];
+    {
+        const f32x4* src = X + ((int64_t)tile * CF_T + t_begin) * KGX * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < KGX; ++g) xc[g] = src[g * 64];
+    }
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(wp + BIAS) + (lane >> 4);
+    const f32x4 br = B4[(0 + W) * 4], bu = B4[(4 + W) * 4], bc = B4[(8 + W) * 4];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+#pragma unroll 8
+        for (int i = threadIdx.x; i < XN4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* WF = lds + lane * 4 + W;                  // + (k-step * 3 + gate) * 256 floats
+    float ring[PF][3];
+    auto fetch = [&](int ks, float (&d)[3]) {
+        ks = ks % KSX;
+        d[0] = WF[(ks * 3 + 0) * 256]; d[1] = WF[(ks * 3 + 1) * 256]; d[2] = WF[(ks * 3 + 2) * 256];
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(p, ring[p]);
+    for (int t = t_begin; t < t_end; ++t) {
+        f32x4 ar = br, au = bu, ac = bc;
+        f32x4 xn[KGX];
+        {
+            const int tn = t + 1 < t_end ? t + 1 : t;      // next step's inputs (last step: a harmless re-read)
+            const f32x4* src = X + ((int64_t)tile * CF_T + tn) * KGX * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < KGX; ++g) xn[g] = src[g * 64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+            const float a0 = ring[ks % PF][0], a1 = ring[ks % PF][1], a2 = ring[ks % PF][2];
+            fetch(ks + PF, ring[ks % PF]);                  // wraps into the next step: same fragments again
+            const float b = xc[ks >> 2][ks & 3];
+            ar = MFMA16(a0, b, ar);
+            au = MFMA16(a1, b, au);
+            ac = MFMA16(a2, b, ac);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4* dst = XP + (((int64_t)tile * CF_T + t) * 2 + dir) * 12 * 64 + lane;
+        dst[(0 + W) * 64] = ar; dst[(4 + W) * 64] = au; dst[(8 + W) * 64] = ac;
+#pragma unroll
+        for (int g = 0; g < KGX; ++g) xc[g] = xn[g];
+    }
+}
+
+// chunks of steps per (tile, direction) for gru_xproj_lds_kernel: the count that minimises rounds x (staging + steps per chunk),
+// in 0.01 us (staging the x region ~2.5 us at Cin = 128, a step = 96 MFMAs of 32 cycles per wave)
+static inline int cf_xproj_plan(int n_tiles, int n_cu, int cin) {
+    const int stage = cin >= 128 ? 250 : 80, step = cin >= 128 ? 128 : 32;
+    const int slots = std::max(1, n_cu) * (cin >= 128 ? 1 : 4);            // resident workgroups: 96 KiB of LDS each at Cin = 128
+    int best = 1, best_cost = 1 << 30;
+    for (int c = 1; c <= CF_T; ++c) {
+        const int tl = (CF_T + c - 1) / c;
+        if ((CF_T + tl - 1) / tl != c) continue;                           // (only chunk counts that leave no empty chunk)
+        const int rounds = (2 * n_tiles * c + slots - 1) / slots;
+        const int cost = rounds * (stage + tl * step);
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
 template <int CIN, bool LAST>
 __global__ __launch_bounds__(256, 1) void gru_layer_coop_kernel(const float* __restrict__ wpack, const f32x4* __restrict__ X,
                                                                 f32x4* __restrict__ Y, float* __restrict__ P, int n_tiles,

@@ -519,3 +519,27 @@ def test_bf16x3_pipelined_kernel_agrees_with_unpipelined(ckpt_weights, monkeypat
         assert np.abs(eng.infer_host(x) - oracle.forward(x, w, np.float64)).max() < TOL
     finally:
         eng.close()
+
+
+def test_xproj_through_lds_is_bit_identical(ckpt_weights, monkeypatch):
+    """Small calls hoist the x projection out of the recurrence (gru_coop.hpp).  gru_xproj_lds_kernel (weights staged in LDS,
+    a chunk of steps per workgroup) against round 2's gru_xproj_kernel (every wave its fragments straight from L2;
+    CATFISH_XPROJ_LDS=0 behind the debug switch): same bias-first, k-ascending accumulation, so the same bits -- at one tile,
+    a single read, the chunk planner's other regimes and the last hoisted size; and the hoisted calls equal the same
+    windows inside a throughput-regime call."""
+    from catfish_amd.engine import HipEngine
+    monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=8192)
+    try:
+        hoisted_max = eng.launch_regimes()["hoist_max"]
+        x = np.random.default_rng(4).normal(0, 1.4, size=(8000, 35)).astype(np.float32)
+        big = eng.infer_host(x)                                                  # throughput kernels
+        for n in (1, 16, 118, 130, 300, 512, hoisted_max):
+            monkeypatch.delenv("CATFISH_XPROJ_LDS", raising=False)
+            new, new_logits = eng.infer_host(x[:n], return_logits=True)
+            monkeypatch.setenv("CATFISH_XPROJ_LDS", "0")
+            old, old_logits = eng.infer_host(x[:n], return_logits=True)
+            assert np.array_equal(new, old) and np.array_equal(new_logits, old_logits), n
+            assert np.array_equal(new, big[:n * 35]), n
+    finally:
+        eng.close()
