@@ -110,6 +110,16 @@ __global__ __launch_bounds__(256, 1) void gru_bf16x3_pipe_kernel(const char* __r
     const int hh = lane >> 5;
     const far_lds<bf16x8> WAF(reinterpret_cast<const bf16x8*>(lds) + lane);     // + (product * 2 + part) * 64
     const f32x4* BI = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + gb_bias_off(CIN, 2)) + hh * 4;
+    f32x16 bias[6];                                         // CF_X3_BIAS_C: the C operand of the MFMA that opens an accumulator
+    if constexpr (CF_X3_BIAS_C) {
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 b = BI[mt * 8 + c4];
+                bias[mt][4 * c4 + 0] = b.x; bias[mt][4 * c4 + 1] = b.y; bias[mt][4 * c4 + 2] = b.z; bias[mt][4 * c4 + 3] = b.w;
+            }
+    }
     float dw[32];                                           // LAST: this lane's rows of final_fully_connected/kernel
     if constexpr (LAST) {
         const float* DWp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + gb_dense_off(CIN, 2)) + hh * 16;
@@ -162,8 +172,10 @@ __global__ __launch_bounds__(256, 1) void gru_bf16x3_pipe_kernel(const char* __r
             else if constexpr (d.src == G::SRC_XA) b = xa[d.kb][part];
             else b = xb[d.kb][part];
             const bf16x8 a = ar[p % DA][sub == 2 ? 1 : 0];                 // A: hi, hi, lo   (prod<2>'s order)
-            if constexpr (!(CF_X3_ABL & 2)) acc[d.mt] = MFMA32B(a, b, acc[d.mt]);
-            else asm volatile("" ::"v"(a), "v"(b));
+            constexpr bool opens = CF_X3_BIAS_C && sub == 0 && G::first_prod(d.mt) == p;      // bias + ... : the accumulation starts here
+            if constexpr (CF_X3_ABL & 2) asm volatile("" ::"v"(a), "v"(b));
+            else if constexpr (opens) acc[d.mt] = MFMA32B(a, b, bias[d.mt]);
+            else acc[d.mt] = MFMA32B(a, b, acc[d.mt]);
             // the hi fragment is dead after the second MFMA, the lo fragment after the third
             if constexpr (sub == 1 && !(FINAL && p + DA >= G::OC)) ar[p % DA][0] = WAF[(G::prod((p + DA) % NSEQ).frag * 2 + 0) * 64];
             if constexpr (sub == 2 && !(FINAL && p + DA >= G::OC)) ar[p % DA][1] = WAF[(G::prod((p + DA) % NSEQ).frag * 2 + 1) * 64];
@@ -233,8 +245,10 @@ __global__ __launch_bounds__(256, 1) void gru_bf16x3_pipe_kernel(const char* __r
             ar[(G::OC + q) % DA][0] = WAF[(G::prod(G::OC + q).frag * 2 + 0) * 64];
             ar[(G::OC + q) % DA][1] = WAF[(G::prod(G::OC + q).frag * 2 + 1) * 64];
         }
+        if constexpr (!CF_X3_BIAS_C) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) load_bias(q);
+            for (int q = 0; q < 16; ++q) load_bias(q);
+        }
         x3_for(std::make_integer_sequence<int, G::GC>{}, [&](auto k_) __attribute__((always_inline)) {
             mfma_gap(std::integral_constant<int, 3 * G::OC + decltype(k_)::value>{}, std::false_type{}, x1, x0);
             __builtin_amdgcn_sched_barrier(0);

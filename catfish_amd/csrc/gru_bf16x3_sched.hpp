@@ -14,6 +14,14 @@
 #define CF_X3_XCA 8
 #endif
 
+// 0: an accumulator's bias row is re-read from LDS every step (24 ds_read_b128, the LB micro-ops);
+// 1: it is the C operand of the first MFMA into the accumulator (96 registers hold the six rows for the whole kernel) -- fewer
+//    LDS reads and no LB ops, but measured 3.7 % SLOWER on the whole bf16x3 pass (1.183 vs 1.139 ms, three interleaved rounds
+//    on one box, tools/ab_x3_variants.sh; profiles/r04_x3_ab_bias_nt.log): kept as an A/B switch only
+#ifndef CF_X3_BIAS_C
+#define CF_X3_BIAS_C 0
+#endif
+
 namespace x3 {
 
 enum : int {
@@ -64,6 +72,14 @@ struct geom {
         if (i < HR0) { const int q = i - XU0; return {(q >> 1) * 6 + 2 + (q & 1), 2 + (q & 1), SRC_XB, q >> 1}; }       // C: Wx_u x_{s+1}, first part
         const int q = i - HR0;
         return {NX + (q >> 1) * 4 + (q & 1), q & 1, SRC_HP, q >> 1};                                                    // C: Wh_r h'
+    }
+    // the product that opens accumulator mt: cyclic order from phase C, where the next step's r and u accumulators start
+    static __host__ __device__ constexpr int first_prod(int mt) {
+        for (int k = 0; k < NSEQ; ++k) {
+            const int i = (OC + k) % NSEQ;
+            if (prod(i).mt == mt) return i;
+        }
+        return -1;
     }
 };
 
@@ -142,7 +158,7 @@ constexpr bool pair_done(int e) { return e >= 0 && e < 32 && (e & 1); }     // t
 //   LX  x_{s+2} into the buffer of x_s, in C: its last MFMA (Wx_c) issued in B, and it is next read a whole step later
 template <class P> constexpr void list_a(P& p, int L) {
     for (int k = 0; k < 32 + 7 * L; ++k) {
-        if (k < 8) p(LB, 16 + k);
+        if (!CF_X3_BIAS_C && k < 8) p(LB, 16 + k);
         if (elem(k)) p(AE, k);
         if (elem(k - L)) p(AR1, k - L);
         if (elem(k - 2 * L)) p(AR2, k - 2 * L);
@@ -155,7 +171,7 @@ template <class P> constexpr void list_a(P& p, int L) {
 }
 template <class P> constexpr void list_b(P& p, int L) {
     for (int k = 0; k < 32 + 2 * L; ++k) {
-        if (k < 32 && (k & 3) == 0) p(LB, k >> 2);
+        if (!CF_X3_BIAS_C && k < 32 && (k & 3) == 0) p(LB, k >> 2);
         if (elem(k)) p(BE, k);
         if (elem(k - L)) p(BR1, k - L);
         if (elem(k - 2 * L)) p(BR2, k - 2 * L);
@@ -163,7 +179,7 @@ template <class P> constexpr void list_b(P& p, int L) {
 }
 template <class P> constexpr void list_c(P& p, int L, bool last, int kbx) {
     for (int k = 0; k < 32 + 10 * L; ++k) {
-        if (k < 8) p(LB, 8 + k);
+        if (!CF_X3_BIAS_C && k < 8) p(LB, 8 + k);
         if (kbx >= 8 ? (k < 32 && !(k & 1)) : (k < 32 && (k & 7) == 4)) p(LX, kbx >= 8 ? k >> 1 : k >> 3);
         if (elem(k)) p(CE, k);
         if (elem(k - L)) p(CR1, k - L);
@@ -241,7 +257,7 @@ constexpr bool sched_ok(const sched_t<geom<CIN>::NGAP>& s) {
         // ... and the old hp[kb] must have been read by Wh_u h (phase A) before CP1 overwrites it: phases are disjoint
     }
     // the accumulators' bias rows: after the gate's last exp2, before the first MFMA into the accumulator
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < (CF_X3_BIAS_C ? 0 : 8); ++q) {
         if (s.gap[LB][16 + q] >= 3 * G::XC0) return false;                  // acc_c: before A's first Wx_c product
         if (s.gap[LB][q] <= s.gap[AE][31] || s.gap[LB][q] >= c0) return false;
         if (s.gap[LB][8 + q] <= s.gap[BE][31] || s.gap[LB][8 + q] >= 3 * G::XU0) return false;
