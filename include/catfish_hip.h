@@ -204,7 +204,9 @@ int64_t cf_chunks_json(const char* keys, const int64_t* key_bounds, int64_t n_re
  * paths: the names as NUL-terminated strings back to back, path_bounds[n_files + 1] their byte offsets; out / capacity: the
  * int16 buffer (e.g. pinned staging memory) and its size in samples; lengths[n_files] receives every read's sample count,
  * *total (may be NULL) their sum (also when they do not fit capacity).  CF_ERR_INVALID names the first file that is
- * missing or is not such an array in cf_last_error(): the caller then takes its general loader for that batch. */
+ * missing or is not such an array in cf_last_error(): the caller then takes its general loader for that batch.  A file is
+ * judged by its first 4 KiB (its header) and its size before it is read: only regular files whose header matches their
+ * length are read whole.  CF_ERR_NOMEM: the tables or a read did not fit host memory (no C++ exception leaves the call). */
 int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
                       int64_t* lengths, int64_t* total, int32_t n_threads);
 
