@@ -543,3 +543,21 @@ def test_xproj_through_lds_is_bit_identical(ckpt_weights, monkeypatch):
             assert np.array_equal(new, big[:n * 35]), n
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n_layers,n", [(1, 200), (2, 1100)])
+def test_bf16x3_pipelined_kernel_at_other_depths(n_layers, n):
+    """The pipelined bf16x3 kernel's other instantiations: a one-layer stack runs the 32-input kernel with the fused dense
+    partial (<32, true>), two layers run <32, false> and <128, true> back to back; random weights against the fp64 oracle,
+    and a call split in two gives the same bits as one."""
+    from catfish_amd.engine import HipEngine
+    w = oracle.random_weights(seed=40 + n_layers, n_layers=n_layers)
+    x = np.random.default_rng(n_layers).normal(0, 1.3, size=(n, 35)).astype(np.float32)
+    eng = HipEngine(w, n_layers=n_layers, device=0, max_windows_per_pass=4096, precision="bf16x3")
+    try:
+        got = eng.infer_host(x)
+        m = min(n, 200)
+        assert np.abs(got[:m * 35] - oracle.forward(x[:m], w, np.float64, n_layers=n_layers)).max() < TOL
+        assert np.array_equal(np.concatenate([eng.infer_host(x[:n // 3]), eng.infer_host(x[n // 3:])]), got)
+    finally:
+        eng.close()
