@@ -1379,7 +1379,12 @@ template <int CIN>
 static void launch_xproj(cf_model* m, const float* wpack, const float* X, int n_tiles, hipStream_t s) {
     const int lds_env = cf_knob("CATFISH_XPROJ_LDS") ? atoi(cf_knob("CATFISH_XPROJ_LDS")) : 1;
     if (lds_env) {
-        const int chunks = cf_xproj_plan(n_tiles, m->n_cu, CIN);
+        int chunks = cf_xproj_plan(n_tiles, m->n_cu, CIN);
+        if (cf_knob("CATFISH_XPROJ_CHUNKS")) {                                   // A/B knob for tools/: another valid chunk count
+            const int c = std::max(1, std::min(CF_T, atoi(cf_knob("CATFISH_XPROJ_CHUNKS"))));
+            const int tl = (CF_T + c - 1) / c;
+            chunks = (CF_T + tl - 1) / tl;
+        }
         hipLaunchKernelGGL((gru_xproj_lds_kernel<CIN>), dim3(n_tiles * chunks, 2), dim3(256), gru_x_floats(CIN) * 4, s, wpack,
                            reinterpret_cast<const f32x4*>(X), reinterpret_cast<f32x4*>(m->d_xp), n_tiles, chunks);
     } else {
