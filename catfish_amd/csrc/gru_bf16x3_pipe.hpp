@@ -1,9 +1,11 @@
 // gru_bf16x3_pipe.hpp -- biGRU layer in bf16x3 (NP = 2: split-operand fp32 emulation, three bf16 MFMAs per product),
-// software-pipelined for ONE wave per SIMD.  Included by catfish_hip.hip after gru_bf16.hpp (same weight blob, same
-// activation layout, same arithmetic per element and the same accumulation order per accumulator as
-// gru_layer_bf16_kernel<CIN, LAST, 2>, so the two kernels are bit-identical; rnn_class.py:142-175).
+// software-pipelined for ONE wave per SIMD.  Included by catfish_hip.hip after gru_bf16.hpp: same weight blob, same
+// activation layout, same products in the same order per accumulator and the same activation arithmetic as
+// gru_layer_bf16_kernel<CIN, LAST, 2> (rnn_class.py:142-175).  (Not its bits: that kernel's compiler contracts most of its
+// `r*h - hi` into an fma, which moves single bf16 lo parts by one ulp; every operation here is pinned.  The two agree to 1.2e-6
+// in probability and have the same error against the fp64 oracle: tests/test_gpu_parity.py.)
 //
-// Why a kernel of its own: bf16x3 is matrix-pipe bound (216 MFMAs of 32 cycles per 32-window step against ~3.9 k cycles of
+// Why a kernel of its own: bf16x3 is matrix-pipe bound (216 MFMAs of 32 cycles per 32-window step against ~4 k cycles of
 // vector issue), but the round-1 kernel runs a step as [MFMAs] -> [sigmoid] -> [MFMAs] -> [sigmoid, tanh] and leaves the pipe
 // idle half of the time.  gru_bf16_pipe.hpp's structure does not carry over as it stands: with hi + lo parts the two x
 // buffers, the operand fragments of h and r*h and the A ring double, ~430 registers.  So this kernel takes the whole
@@ -12,21 +14,21 @@
 // are spread evenly (MI355X_MICROARCH.md, 'one wave per SIMD: single-issue instructions hidden per gap'); whatever a gap
 // carries beyond 24 cycles of issue stalls the matrix pipe and is never recovered.
 //
-// Schedule of one step (product = 3 MFMAs: w_hi*a_hi, w_hi*a_lo, w_lo*a_hi; KBX = CIN/16 k-blocks of x):
+// Schedule of one step (product = 3 MFMAs: w_hi*a_hi, w_hi*a_lo, w_lo*a_hi; KBX = CIN/16 k-blocks of x; XUA, XCA: x3::geom):
 //
-//   A  acc_u += Wh_u h                8 products      ||  r = sigmoid(acc_r), r*h -> bf16 hi + lo (rp)
-//      acc_c  = b_c + Wx_c x_s        XCA of 2 KBX
-//   B  acc_c += Wx_c x_s (rest), then Wh_c rp  8      ||  u = sigmoid(acc_u) (kept in registers of its own), x_{s+2} loads
-//   C  acc_r  = b_r + Wx_r x_{s+1}    2 KBX           ||  c = tanh(acc_c), h' = c + u (h - c), h' -> bf16 hi + lo (hp), stores
-//      acc_u  = b_u + Wx_u x_{s+1}    2 KBX
+//   A  acc_u += Wx_u x_s (last XUA), then Wh_u h  8   ||  r = sigmoid(acc_r), r*h -> bf16 hi + lo (rp)
+//      acc_c  = b_c + Wx_c x_s        first XCA
+//   B  acc_c += Wx_c x_s (rest), then Wh_c rp  8      ||  u = sigmoid(acc_u) (kept in registers of its own)
+//   C  acc_r  = b_r + Wx_r x_{s+1}    2 KBX           ||  c = tanh(acc_c), h' = c + u (h - c), h' -> bf16 hi + lo (hp), stores,
+//      acc_u  = b_u + Wx_u x_{s+1}    first 2 KBX - XUA   loads of x_{s+2}
 //      acc_r += Wh_r h'               8, k-block kb once hp[kb] is complete
 //
 // The phases are sized by their vector work (C carries most of it), which is what the spare registers buy: with u out of its
 // accumulator the x projection of BOTH gates of step s + 1 rides behind the h update of step s.  The vector work is cut into
 // single instructions (one v_exp, one v_rcp, one add ...), listed per phase in software-pipelined order (element k's exp2,
 // element k-L's add, element k-2L's rcp ...) and packed into the phase's gaps by cumulative issue cost at compile time
-// (x3::make_sched): every gap gets the same share.  A sched_barrier per gap pins the order; static_asserts check that
-// every MFMA finds its operands complete in program order.
+// (x3::make_sched): every gap gets the same load.  A sched_barrier per gap pins the order; static_asserts check that
+// every MFMA finds its operands complete in program order.  DESIGN.md section 4 has the measurements and what bounds it.
 #pragma once
 
 // Diagnostic build: s_memtime stamps around the three phases of every step, summed per wave and written to the (otherwise
@@ -39,7 +41,8 @@
 #ifndef CF_X3_ABL
 #define CF_X3_ABL 0
 #endif
-// non-temporal hint on the layer output stores (bit 0: on, measured -3 % on the mid layer) and the layer input loads (bit 1)
+// non-temporal hint on the layer output stores (bit 0: on, measured -2..3 % on the mid layer) and the layer input loads (bit 1:
+// measured neutral, off)
 #ifndef CF_X3_NT
 #define CF_X3_NT 1
 #endif
