@@ -24,4 +24,14 @@ PREC=bf16x3 bash tools/pmc_pass.sh SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_
 PREC=bf16x3 bash tools/pmc_pass.sh SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE > $OUT/pmc_bf16x3_b.jsonl 2>&1
 echo "pmc done" >> $OUT/commit.txt
 python tools/merge_pmc.py $COMMIT bf16x3=$OUT/pmc_bf16x3_a.jsonl,$OUT/pmc_bf16x3_b.jsonl > $OUT/pmc.json
+# diagnostic builds of the bf16x3 kernel (tools/build_x3_variants.sh stamp abl:1 abl:2, built before the run: tools/x3var/ travels)
+if [ -f tools/x3var/libcatfish_x3_stamp_8_8_0.so ]; then
+  CATFISH_DEBUG_KNOBS=1 CATFISH_HIP_LIB=tools/x3var/libcatfish_x3_stamp_8_8_0.so python tools/exp_x3_stamps.py 2>&1 | grep -v "amdgpu.ids" > $OUT/x3_stamps.log
+  X3_LAYERS=2 CATFISH_DEBUG_KNOBS=1 CATFISH_HIP_LIB=tools/x3var/libcatfish_x3_stamp_8_8_0.so python tools/exp_x3_stamps.py 2>&1 | grep -v "amdgpu.ids" > $OUT/x3_stamps_layer0.log
+fi
+if [ -f tools/x3var/libcatfish_x3_abl1.so ]; then
+  bash tools/ab_x3_variants.sh 2 default tools/x3var/libcatfish_x3_abl1.so tools/x3var/libcatfish_x3_abl2.so > $OUT/x3_ablation.log 2>&1
+fi
+python tools/exp_latency_parts.py > $OUT/latency_parts.log 2>/dev/null
+python tools/bench_latency.py > $OUT/latency.json 2>/dev/null
 echo "all done" >> $OUT/commit.txt
