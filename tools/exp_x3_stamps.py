@@ -24,6 +24,9 @@ if n_layers == 3:
 else:
     from oracle import catfish_oracle as oracle
     w = oracle.random_weights(seed=1, n_layers=n_layers)
+if os.environ.get("X3_ZERO_WEIGHTS"):                    # every MFMA operand zero (weights, biases, hence h): the DVFS check --
+    w = {k: np.zeros_like(v) for k, v in w.items()}      # same instruction stream, no data toggling; does the clock rise?
+    w = {k: (np.ones_like(v) if k.endswith("moving_variance") else v) for k, v in w.items()}
 n_win = int(os.environ.get("X3_WINDOWS", 256 * 118))
 eng = HipEngine(w, n_layers=n_layers, device=0, max_windows_per_pass=n_win, precision="bf16x3")
 x = torch.randn(n_win, 35, device="cuda")
