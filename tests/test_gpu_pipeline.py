@@ -1002,3 +1002,36 @@ def test_cli_two_ranks_share_one_gpu(tmp_path, ckpt_weights):
             assert nonhp[name] == non
         else:
             assert name not in hp
+
+
+def test_configs1_at_full_size_is_invariant_to_the_launch_size(ckpt_weights):
+    """BASELINE configs[1] at its full size -- 10 000 synthetic 4096-sample reads, fp32 -- which the oracle cannot follow
+    (it classifies ~75 k samples/s per core; this is 41 M): windows are independent, so how many reads share a launch must
+    not matter.  The benchmark's 256-read launches (per-layer biGRU launches, four chip rounds each) against 1024-read
+    launches (120 832 windows: the dynamically scheduled single launch of all three layers) give bit-identical
+    probabilities and identical spans for every read; lengths come back exact; three reads are checked against the fp64
+    oracle at the 1e-4 gate; and device normalisation + post-processing make the spans equal the per-read oracle pipeline."""
+    from catfish_amd import batching
+    from catfish_amd.engine import HipEngine
+    n_reads, length = 10000, 4096
+    dacs = list(oracle.synthetic_dac(n_reads, length, seed=0))
+    eng = HipEngine(ckpt_weights, device=0, max_windows_per_pass=1024 * 118)
+    try:
+        small, p_small = batching.infer_reads_dac(eng, dacs, max_windows=256 * 118, return_probs=True)
+        digest_small = [float(p.sum(dtype=np.float64)) for p in p_small]
+        keep = {i: p_small[i].copy() for i in (0, 4999, 9999)}
+        del p_small
+        big, p_big = batching.infer_reads_dac(eng, dacs, max_windows=1024 * 118, return_probs=True)
+        assert [n for _s, n in small] == [length] * n_reads == [n for _s, n in big]
+        assert small == big
+        assert digest_small == [float(p.sum(dtype=np.float64)) for p in p_big]
+        for i, p in keep.items():
+            assert np.array_equal(p, p_big[i])
+            x, _pad = oracle.pad_and_window(oracle.normalize_raw_signal(dacs[i]))
+            want = oracle.forward(x, ckpt_weights, np.float64)[:length]
+            assert np.abs(p - want).max() < 1e-4
+            lab = oracle.correct_short(oracle.class_from_threshold(oracle.forward(x, ckpt_weights, np.float32)[:length]))
+            assert big[i][0] == (oracle.hp_in_pred(lab) if lab.any() else [])
+        eng.check_error()
+    finally:
+        eng.close()
