@@ -59,7 +59,7 @@ struct geom {
     enum : int { SRC_HP, SRC_XA, SRC_RP, SRC_XB };
     struct prod_t { int frag, mt, src, kb; };
     // product i of a step -> blob product, accumulator M-tile (r 0,1  u 2,3  c 4,5), B operand.  Per accumulator the order is
-    // bias, x k-blocks ascending, h k-blocks ascending: gru_layer_bf16_kernel's order, hence its bits.
+    // bias, x k-blocks ascending, h k-blocks ascending: gru_layer_bf16_kernel's order.
     static __host__ __device__ constexpr prod_t prod(int i) {
         if (i < XUA) { const int q = XUC + i; return {(q >> 1) * 6 + 2 + (q & 1), 2 + (q & 1), SRC_XA, q >> 1}; }       // A: Wx_u x_s, the rest
         if (i < XC0) { const int q = i - XUA; return {NX + (q >> 1) * 4 + 2 + (q & 1), 2 + (q & 1), SRC_HP, q >> 1}; }  // A: Wh_u h
