@@ -492,3 +492,39 @@ def test_native_chunk_rules_property_based():
         assert b"{" + non_text + b"}" == json.dumps(want_non).encode()
 
     check()
+
+
+def test_bf16x3_schedule_compiles_on_the_host_and_is_consistent(tmp_path):
+    """The instruction schedule of gru_bf16x3_pipe_kernel is plain constexpr C++ (catfish_amd/csrc/gru_bf16x3_sched.hpp): built
+    here with g++ through tools/x3_sched_dump.cpp for all four kernel variants.  Every variant must pass its own
+    program-order check (an MFMA never reads an operand that a later gap produces), schedule every micro-op exactly once,
+    and -- for the 128-input layers, which are meant to hide their vector work -- load no gap with more than 44 issue cycles
+    and no phase with more than 25 on average (24 fit behind an MFMA)."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ is not installed")
+    exe = str(tmp_path / "x3dump")
+    build = subprocess.run(["g++", "-std=c++17", "-DX3_SCHED_DUMP", "-o", exe, os.path.join(ROOT, "tools", "x3_sched_dump.cpp")],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert build.returncode == 0, build.stdout
+    for cin, last in ((128, False), (128, True), (32, False), (32, True)):
+        args = [exe, str(cin)] + (["last"] if last else ["x"]) + ["-v"]
+        out = subprocess.run(args, stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout
+        head = out.splitlines()[0]
+        assert " ok 1," in head, head
+        gaps = int(re.search(r"gaps (\d+)", head).group(1))
+        assert gaps == (216 if cin == 128 else 108)
+        ops = re.findall(r" ([A-Z]+[0-9]?[A-Z]?[0-9]?)(\d+)", "\n".join(l.split(":", 1)[1] for l in out.splitlines() if re.match(r"\s*\d+  p", l)))
+        names = [a + b for a, b in ops]
+        assert len(names) == len(set(names)), "a micro-op was scheduled twice"
+        for kind, count in (("AE", 32), ("AR2", 32), ("AM", 32), ("AP4", 16), ("BE", 32), ("BR2", 32), ("CE", 32), ("CH", 32), ("CP4", 16),
+                            ("LX", cin // 8), ("LB", 24), ("CL", 32 if last else 0), ("CS", 0 if last else 8)):
+            assert sum(1 for n in names if re.fullmatch(kind + r"\d+", n)) == count, (cin, last, kind)
+        if cin == 128:
+            assert int(re.search(r"heaviest gap (\d+)", head).group(1)) <= 44
+            for line in out.splitlines():
+                m = re.search(r"= ([0-9.]+) per gap", line)
+                if m:
+                    assert float(m.group(1)) <= 25.0, line
