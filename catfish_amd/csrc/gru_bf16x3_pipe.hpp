@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void gru_bf16x3_pipe_kernel(const char* __r
             x3_for(std::make_integer_sequence<int, NGAP>{}, [&](auto g_) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_)::value;
                 mfma_gap(g_, final_, xa, xb);
-                x3_for(std::make_integer_sequence<int, T::S.MAXO>{}, [&](auto q_) __attribute__((always_inline)) { vop(g_, q_, final_, xa, xb, s, t); });
+                x3_for(std::make_integer_sequence<int, T::S.n[g]>{}, [&](auto q_) __attribute__((always_inline)) { vop(g_, q_, final_, xa, xb, s, t); });
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (CF_X3_STAMP && (g == G::GA - 1 || g == G::GA + G::GB - 1 || g == NGAP - 1)) {
                     const long long tb_ = (long long)__builtin_amdgcn_s_memtime();
