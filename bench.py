@@ -45,6 +45,7 @@ SHARDED_READS_PER_RANK = 12500      # BASELINE configs[2]: 100 000 reads over 8 
 CONFIG4_READS = 10000               # BASELINE configs[3]
 CONFIG4_MAX_WINDOWS = 131072        # windows per packed launch: the regime catfish_amd.cli uses for big jobs (cli.run_pipeline)
 CONFIG4_PARITY_READS = 32           # reads of it checked against the fp32 oracle (shortest, longest, 30 spread over the rest)
+RANK_NOTES = {}                     # what this rank's informational legs want in its entry of the line's ``ranks`` list
 
 
 def squiggle_dac(rng, length):
@@ -150,7 +151,19 @@ def nearer_roof(roof, precision, samples, seconds):
                                       "frac": pipe_frac, "mfma_per_product": int(issue_factor),
                                       "tuned_gemm_on_random_data_tflops": 1247.0,
                                       "frac_of_that": roof["achieved"] * issue_factor / 1247.0}
-    if hbm_view["frac"] > pipe_frac:
+    # The HBM side of the comparison is the LARGER of the algorithmic-bytes fraction and -- when a stored PMC record exists -- the
+    # measured fabric traffic's fraction (both directions of a layer re-read the input slab: traffic is ~1.5x the slabs).  ``frac``
+    # and ``achieved`` stay algorithmic (the contract of the line); ``decided_by`` says which quantities were compared, and a gap
+    # below 10 % is called what it is: a near tie, the kernel sits against both roofs.
+    hbm_frac = max(hbm_view["frac"], hbm_view.get("traffic_rate_frac", 0.0))
+    hbm_what = ("measured HBM traffic (stored PMC record) %.3f of peak" % hbm_view["traffic_rate_frac"]
+                if hbm_view.get("traffic_rate_frac", 0.0) > hbm_view["frac"] else "algorithmic HBM bytes %.3f of peak" % hbm_view["frac"])
+    pipe_what = ("ISSUED matrix-pipe FLOPs (%d MFMAs per product) %.3f of peak" % (int(issue_factor), pipe_frac)
+                 if issue_factor != 1.0 else "algorithmic matrix FLOPs %.3f of peak" % pipe_frac)
+    near_tie = abs(hbm_frac - pipe_frac) <= 0.10 * max(hbm_frac, pipe_frac)
+    roof["near_tie"] = bool(near_tie)
+    roof["decided_by"] = "%s against %s%s" % (hbm_what, pipe_what, "; within 10 %: mfma~hbm, a near tie" if near_tie else "")
+    if hbm_frac > pipe_frac:
         mfma_view = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
         roof.update(bound="hbm", achieved=hbm, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm / PEAK_HBM_GBS, mfma_view=mfma_view,
                     hbm_detail=hbm_view)
@@ -310,7 +323,16 @@ def leg_config5(weights, local_rank, torch):
             tr.train_step(x, y)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        out["batch_%d" % batch] = {"ms_per_step": dt * 1e3, "windows_per_s": batch / dt, "native_step": bool(tr.step_impl is not None)}
+        # forward + backward of the same graph ~ 3x the forward's FLOPs (backward = dX and dW products of every forward product)
+        flops = 3.0 * FLOP_PER_SAMPLE * WINDOW * batch
+        ach = flops / dt / 1e12
+        out["batch_%d" % batch] = {"ms_per_step": dt * 1e3, "windows_per_s": batch / dt, "native_step": bool(tr.step_impl is not None),
+                                   "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "flop_per_step": flops,
+                                                "what": "whole training step (not one kernel): 3 x forward FLOPs per window (389 504 x 35) / step "
+                                                        "time / fp32 MFMA peak"
+                                                        + ("; at the reference's batch of 256 windows the step is ~30 dependent launches of 16 "
+                                                           "tiles each -- latency-bound, 6 % of the chip's workgroup slots" if batch == 256 else "")}}
         if batch == 256:
             gpu = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)
             cpu = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
@@ -374,6 +396,7 @@ def leg_sharded_gather(eng, weights, rank, world, dist, torch):
     table = sharding.infer_reads_sharded(eng, reads, lengths=lengths, max_samples_per_batch=batch, batch_runner=runner,
                                          rank=rank, world_size=world, gather_group=group, as_table=True)
     dt = time.perf_counter() - t0                          # rank 0: includes the gather of every rank's results
+    RANK_NOTES["sharded_gather_s"] = dt
     t1 = time.perf_counter()
     as_lists = table.expand() if rank == 0 else None      # the reference's result type, built once on rank 0 (timed apart)
     dt_lists = time.perf_counter() - t1
@@ -400,8 +423,9 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
     """The product entry point on BASELINE configs[2]'s shape, files -> JSON: ``catfish_amd.cli.run_pipeline`` (the body of
     catfish/catfish:23-94 up to the split step) over a directory of 12 500 x 4096-sample int16 reads per rank.  Every rank
     loads, classifies AND merges / centres / complements its own files (catfish/catfish:50-82), formats its part of the two
-    JSON documents and writes it at its offset.  Timed from the end of set-up (network loaded on every rank) to the
-    documents on disk; page cache warm (the files were just written)."""
+    JSON documents and writes it at its offset.  Timed: everything but the network load -- output directories, the listing of the
+    input directory (catfish/catfish:49-50; it grows with the job), classification, merge tail, documents on disk; page cache
+    warm (the files were just written)."""
     import contextlib
     import io
     import shutil
@@ -427,6 +451,7 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
         if world > 1:
             dist.barrier()
         timings = {}
+        host_group = sharding.host_gather_group() if world > 1 else None
         sink = io.StringIO()
         t0 = time.perf_counter()
         failure = None
@@ -437,13 +462,21 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
         except Exception as exc:                              # noqa: BLE001 -- raised below, after the barrier every rank reaches
             failure = exc
         total = time.perf_counter() - t0
+        per_rank = [None] * world
+        mine = {k: timings.get(k) for k in ("listing_s", "model_s", "infer_s", "chunks_s", "write_s")}
+        mine.update(rank=rank, total_s=total, failed=None if failure is None else "%s: %s" % (type(failure).__name__, failure))
         if world > 1:
-            dist.barrier()
+            dist.all_gather_object(per_rank, mine, group=host_group)      # doubles as the barrier every rank reaches
+        else:
+            per_rank = [mine]
+        RANK_NOTES.setdefault("cli_end_to_end", {}).update(mine)
         if failure is not None:
             raise failure
         if rank != 0:
             return None
-        dt = total - timings["setup_s"]
+        # the network load is set-up; the directory listing (names on every rank, sizes of a rank's block, the agreement) is part
+        # of the job -- it grows with the number of files -- and is counted
+        dt = total - timings["model_s"]
         post = timings.get("write_s", 0.0)
         with open(os.path.join(root, "out", "TEMP", "hp_positions.json")) as fh:
             hp = json.load(fh)
@@ -453,8 +486,13 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
               and len(hp) == res["reads_with_hp"] and sum(len(v) for v in hp.values()) == res["hp_chunks"])
         return {"workload": "configs[2] through the CLI: %d files x %d samples (seed 1) over %d rank(s), %d per rank; chunk_size "
                             "1000" % (n_total, READ_LEN, world, SHARDED_READS_PER_RANK),
-                "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "set_up_seconds": timings["setup_s"],
-                "rank0": {"infer_s": timings.get("infer_s"), "chunks_s": timings.get("chunks_s"), "write_s": timings.get("write_s")},
+                "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "model_load_seconds_excluded": timings["model_s"],
+                "listing_s": timings["listing_s"],
+                "timed_region": "output directories + listing of the input directory (every rank: names; its block: sizes; the ranks' "
+                                "agreement) + classification + merge tail + documents on disk; only the network load is left out",
+                "rank0": {"listing_s": timings.get("listing_s"), "infer_s": timings.get("infer_s"), "chunks_s": timings.get("chunks_s"),
+                          "write_s": timings.get("write_s")},
+                "per_rank": per_rank,
                 "rank0_after_classification_frac": post / dt, "reads": n_total, "reads_with_hp": len(hp),
                 "hp_chunks": res["hp_chunks"], "document_bytes": res["bytes"], "n_gpus": world, "results_ok": bool(ok),
                 "what": "int16 .npy files -> per-rank loader thread + ReadPipeline (cf_normalize, cf_infer, cf_postprocess, cf_spans) "
@@ -494,12 +532,21 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launcher_local_rank = local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared_device = None
     if "CATFISH_BENCH_DEVICE" in os.environ:      # rehearsal of the N > 1 path on a box with fewer GPUs than ranks
-        local_rank = int(os.environ["CATFISH_BENCH_DEVICE"])
+        shared_device = local_rank = int(os.environ["CATFISH_BENCH_DEVICE"])
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_res = cpu_baseline()
+
+    # Rank placement BEFORE the first GPU call and the first pinned allocation: this rank (and the loader thread, the library's
+    # file pool and the HIP runtime's threads it will start) runs on the CPUs next to its MI355X -- catfish_amd/placement.py.
+    # After the CPU baseline, which is entitled to every core of the box.
+    from catfish_amd import placement
+    place = placement.bind(launcher_local_rank, local_world,
+                           device_of_rank=(lambda r: shared_device) if shared_device is not None else None)
 
     import torch
     import torch.distributed as dist
@@ -508,27 +555,33 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    backend = None
+    backend, nccl_error, ranks_seen = None, None, 1
     if world > 1:
         # The data path has no collective; the process group only serves the timing barrier and the MAX over
-        # ranks.  RCCL ("nccl") first; if it cannot initialise on this node, fall back to gloo (host barrier).
+        # ranks.  RCCL ("nccl") first; if it cannot initialise on this node, fall back to gloo (host barrier) -- and SAY so in
+        # the line (``collective``): a scaling record must show which library carried the barrier and how many ranks it saw.
         try:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            probe = torch.zeros(1, device=torch.device("cuda", local_rank))
+            probe = torch.ones(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(probe)
             torch.cuda.synchronize()
-            backend = "nccl"
+            backend, ranks_seen = "nccl", int(round(float(probe.item())))
         except Exception as exc:      # pragma: no cover - depends on the node
+            nccl_error = "%s: %s" % (type(exc).__name__, " ".join(str(exc).split())[:400])
             sys.stderr.write("bench.py: nccl init failed (%s); using gloo for the timing barrier\n" % exc)
             if dist.is_initialized():
                 dist.destroy_process_group()
             dist.init_process_group("gloo")
-            backend = "gloo"
+            probe = torch.ones(1)
+            dist.all_reduce(probe)
+            backend, ranks_seen = "gloo", int(round(float(probe.item())))
 
     from catfish_amd.engine import HipEngine
     weights = load_weights()
     eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, n_streams=args.streams,
                     precision=args.precision)
+    pci_bus_id, uuid = eng.device_identity()
+    placement.verify(place, pci_bus_id, launcher_local_rank, local_world)     # the card the runtime gave us against the sysfs guess
 
     # every rank owns its own shard of reads (seeded by rank): no data-path collective
     n_pool = max(READS_PER_STEP, (args.pool_reads // READS_PER_STEP) * READS_PER_STEP)
@@ -563,6 +616,7 @@ def main():
     eng.profile_enable(False)
     eng.check_error()
 
+    dt_local = dt
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -576,8 +630,11 @@ def main():
     if rank == 0:
         # parity gate of the benchmarked configuration against the oracle (not timed): a build that fails it reports no value
         from oracle import catfish_oracle as oracle
-        chk = reads[:2]     # the launch keeps the benchmark's size (rocprof averages stay comparable)
-        got = eng.infer_device(batches[0], out=outs[0]).cpu().numpy()[:2 * 118 * WINDOW].astype(np.float64)
+        # the first, a middle and the last read of the launch (tile 0, the interior, the ragged tail of the last workgroup); the
+        # launch keeps the benchmark's size (rocprof averages stay comparable)
+        picks = [0, READS_PER_STEP // 2, READS_PER_STEP - 1]
+        chk = reads[picks]
+        got = eng.infer_device(batches[0], out=outs[0]).cpu().numpy().reshape(READS_PER_STEP, 118 * WINDOW)[picks].reshape(-1).astype(np.float64)
         want64 = oracle.forward(chk.reshape(-1, WINDOW), weights, np.float64)
         want32 = oracle.forward(chk.reshape(-1, WINDOW), weights, np.float32)
         max_dp = float(np.abs(got - want64).max())
@@ -605,7 +662,8 @@ def main():
                            "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 / peak},
             "kernels_ms": {k: v[0] / v[1] for k, v in kern.items()},
             "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match, "gate": gate,
-                       "min_label_match": min_match, "passed": parity_ok},
+                       "min_label_match": min_match, "passed": parity_ok,
+                       "sample": "reads %s of the %d in one launch (first, middle, last)" % (picks, READS_PER_STEP)},
         }
         if not parity_ok:
             result["unverified_value"] = value
@@ -679,16 +737,56 @@ def main():
                 sys.stderr.write("bench.py: cli_end_to_end leg failed on rank %d: %s\n" % (rank, exc))
         if rank == 0:
             result["cli_end_to_end"] = ce
+    # Who ran what where: every rank's identity, placement and times, gathered over the HOST group (gloo) and printed by rank 0,
+    # so that a scaling record can be judged from the line alone -- did the collective see N ranks, did every rank drive its own
+    # card, which rank was the slow one.  Ranks that SHARE a card are a rehearsal of the launch path, not a measurement.
+    import socket
+    me = {"rank": rank, "local_rank": launcher_local_rank, "device_index": local_rank, "pci_bus_id": pci_bus_id, "uuid": uuid,
+          "device_name": torch.cuda.get_device_name(local_rank), "host": socket.gethostname(), "pid": os.getpid(),
+          "dt_s": dt_local, "ms_per_step": dt_local / args.steps * 1e3, "samples_per_s": args.steps * samples_per_step / dt_local,
+          "cpus": placement.format_cpulist(place.get("cpus") or []), "placement": placement.summary(place)}
+    me.update(RANK_NOTES)
+    ranks = [me]
     if world > 1:
+        from catfish_amd import sharding
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me, group=sharding.host_gather_group())
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        cards = sorted({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks})
+        distinct = len(cards)
+        result["ranks"] = ranks
+        result["collective"] = {"backend": backend, "nccl_init_error": nccl_error, "ranks_seen": ranks_seen,
+                                "what": "timing barrier + MAX over ranks only (no collective on the data path); ranks_seen = all_reduce(sum) of 1 "
+                                        "per rank over that backend" if world > 1 else "single process: no process group"}
+        result["distinct_devices"] = distinct
+        result["visible_devices_rank0"] = torch.cuda.device_count()
+        cpu_sets = [set(placement.parse_cpulist(r["cpus"])) for r in ranks]
+        result["cpu_sets_disjoint"] = bool(all(not (cpu_sets[i] & cpu_sets[j]) for i in range(world) for j in range(i + 1, world)))
+        result["config"]["parallelism"] = ("reads sharded over %d GPU(s), one rank each, no collective" % world if distinct == world else
+                                           "%d ranks on %d device(s): REHEARSAL of the launch path, not a %d-GPU measurement" % (world, distinct, world))
+        if distinct < world:
+            # ranks shared a card (CATFISH_BENCH_DEVICE, or fewer GPUs than ranks): nothing here is an N-GPU number
+            result["rehearsal"] = True
+            result["rehearsal_value"] = result.pop("unverified_value", None) or result["value"]
+            result["value"] = None
+            result["n_ranks"] = world
+            result["n_gpus"] = distinct
+            for leg in ("sharded_gather", "cli_end_to_end"):
+                if isinstance(result.get(leg), dict) and "n_gpus" in result[leg]:
+                    result[leg]["n_ranks"], result[leg]["n_gpus"], result[leg]["rehearsal"] = world, distinct, True
+        else:
+            result["rehearsal"] = False
         # the two host-inclusive rates at the top level, next to ``value`` (which stays the device-resident configs[1] rate the
         # roofline is computed on): what a caller holding host buffers gets from one GPU, and what the whole job delivers from files
         h2h = result.get("host_to_host_pipeline")
         result["host_to_host_value"] = h2h.get("value") if isinstance(h2h, dict) else None
         cli_leg = result.get("cli_end_to_end")
         result["whole_node_end_to_end"] = cli_leg.get("value") if isinstance(cli_leg, dict) else None
+        if result["rehearsal"]:
+            result["rehearsal_whole_node_end_to_end"] = result["whole_node_end_to_end"]
+            result["whole_node_end_to_end"] = None
         print(json.dumps(result))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY GATE FAILED (max |dp| %.3g, label match %.5f): no value reported\n" % (max_dp, match))

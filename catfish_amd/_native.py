@@ -32,7 +32,7 @@ def _lib_path():
 
 
 LIB_PATH = DEFAULT_LIB_PATH
-CF_ABI_VERSION = 4            # include/catfish_hip.h
+CF_ABI_VERSION = 5            # include/catfish_hip.h
 
 CF_OK = 0
 CF_ERR_INVALID = -1
@@ -134,6 +134,7 @@ SYMBOLS = {
     "cf_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cf_profile_slot_name": (C.c_char_p, [C.c_int]),
     "cf_debug_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "cf_device_identity": (C.c_int, [C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]),
     "cf_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "cf_last_error": (C.c_char_p, []),
     "cf_version": (C.c_char_p, []),

@@ -221,8 +221,8 @@ def write_json_documents(directory, table, names, group=None):
         error = None
         try:
             work()
-        except OSError as exc:
-            error = exc
+        except Exception as exc:          # noqa: BLE001 -- ANY failure (MemoryError building the buffer, a TypeError out of pwrite), not
+            error = exc                   # only OSError: a rank that skipped the agreement would leave its peers waiting in it
         try:
             agree_or_raise(error, what, group=group)
         except Exception:

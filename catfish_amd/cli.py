@@ -13,7 +13,6 @@ is not installed the chunk coordinates are written as JSON next to the would-be 
 from __future__ import annotations
 
 import datetime
-import hashlib
 import json
 import os
 
@@ -90,13 +89,19 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
     Returns on every rank the totals ``dict(reads, samples, reads_with_hp, hp_chunks, bytes, files)``; with
     ``gather_table=True`` rank 0's dict also holds ``table``: the ``chunks.ChunkTable`` over all files gathered from the
     ranks (``table.to_dicts(files)`` = the reference's ``hp_dict`` / ``nonhp_dict``).  ``timings`` (optional dict) receives
-    this rank's ``setup_s``, ``infer_s``, ``chunks_s``, ``write_s``.
+    this rank's ``listing_s`` (output directories, the directory listing and the ranks' agreement on it), ``model_s`` (network
+    load up to the ranks' agreement on it), ``setup_s`` (their sum), ``infer_s``, ``chunks_s``, ``write_s`` and ``placement``
+    (the CPUs the rank bound itself to, ``placement.summary``).
     """
     import time
-    from . import chunks, sharding
+    from . import chunks, placement, sharding
     rank, world, local_rank = sharding.dist_env()
+    # before the first GPU call and the first pinned allocation: this rank, its loader thread and the library's file pool run
+    # on the CPUs next to its MI355X (a no-op when the caller -- bench.py -- bound the process already)
+    place = placement.bind(local_rank, device_of_rank=(lambda r: _pick_device(r) if (device is None or r != local_rank) else device))
     own_group = sharding.init_host_group()
     timings = {} if timings is None else timings
+    timings["placement"] = placement.summary(place)
     finished = False
     try:
         # every host-side exchange of this job goes over gloo, also when the caller's default group is RCCL: created
@@ -105,31 +110,39 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         temp_dir = "{}/TEMP".format(os.path.abspath(split_dir))
         input_dir = os.path.abspath(input_dir)
         network_path = os.path.abspath(network_path)
-        model = input_files = file_sizes = max_windows = listing_digest = None
         t1 = datetime.datetime.now()
-        setup_error = None
+        # 1. output directories + the listing (catfish/catfish:35-38, 49-50).  Part of the job: it grows with the directory, so it is
+        # timed apart from the network load (``listing_s``) and counted by the end-to-end benchmark.  Every rank reads the names,
+        # stats only its n/world block, and the ranks agree on names and sizes (``sharding.agree_on_listing``).
+        t_list = time.perf_counter()
+        scanned = listing_error = None
         try:
             if rank == 0:
                 os.makedirs("{}/HP".format(temp_dir))      # raises if they exist, like the reference (:37-38)
                 os.mkdir("{}/nonHP".format(temp_dir))
-            with os.scandir(input_dir) as scan:            # names and sizes in one pass over the directory
-                listing = sorted((entry.name, entry.stat().st_size) for entry in scan)
-            input_files = [name for name, _size in listing]
-            file_sizes = [size for _name, size in listing]
-            # every rank cuts its block out of ITS OWN listing: a file still being copied in, or stale NFS attributes on one
-            # rank, would make the blocks overlap or leave gaps with plausible totals -- so the ranks compare a digest of it
-            listing_digest = hashlib.sha1(repr(listing).encode()).hexdigest()
-            # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
-            # tail instead of 8 % and the three layers go out as one dynamically scheduled launch.
-            max_windows = 131072 if len(input_files) > 400 * world else 32768
+            scanned = sharding.scan_block(input_dir, rank, world)
+        except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
+            listing_error = exc
+        input_files, file_sizes = sharding.agree_on_listing(listing_error, scanned, group=host_group)
+        timings["listing_s"] = time.perf_counter() - t_list
+        # 2. the network (catfish/catfish:40-47), outside what the benchmark counts (``model_s``, up to the ranks' agreement on it)
+        t_model = time.perf_counter()
+        model = setup_error = None
+        # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
+        # tail instead of 8 % and the three layers go out as one dynamically scheduled launch.
+        max_windows = 131072 if len(input_files) > 400 * world else 32768
+        try:
             model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint,
                                                 device=_pick_device(local_rank) if device is None else device,
                                                 max_windows_per_pass=max_windows, precision=precision)
+            if getattr(model, "engine", None) is not None:   # the card the runtime really gave this rank: re-bind if the sysfs guess was another
+                placement.verify(place, model.engine.device_identity()[0], local_rank)
+                timings["placement"] = placement.summary(place)
         except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
             setup_error = exc
-        sharding.agree_or_raise(setup_error, "set-up (output directories, network, listing of the input directory)", group=host_group,
-                                token=listing_digest)
-        timings["setup_s"] = (datetime.datetime.now() - t1).total_seconds()
+        sharding.agree_or_raise(setup_error, "set-up (loading the network, opening the device)", group=host_group)
+        timings["model_s"] = time.perf_counter() - t_model
+        timings["setup_s"] = timings["listing_s"] + timings["model_s"]
         if rank == 0:
             print("Loaded model in {}".format(datetime.datetime.now() - t1))
             print("Checking for homopolymers in raw signal..")

@@ -2307,5 +2307,28 @@ extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
 #include "chunks_host.hpp"
 #include "loader_host.hpp"
 
+// Which card is HIP device `device` of this process (rank placement and the N > 1 bench line: catfish_amd/placement.py)
+extern "C" int cf_device_identity(int device, char* pci_bus_id, int64_t bus_cap, char* uuid_hex, int64_t uuid_cap) {
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(CF_ERR_INVALID, "cf_device_identity: no such device");
+    if (pci_bus_id) {
+        if (bus_cap < 13) return fail(CF_ERR_INVALID, "cf_device_identity: pci_bus_id needs 13 bytes");
+        HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, (int)std::min<int64_t>(bus_cap, 64), device));
+    }
+    if (uuid_hex) {
+        if (uuid_cap < 33) return fail(CF_ERR_INVALID, "cf_device_identity: uuid_hex needs 33 bytes");
+        hipUUID id;
+        HIP_TRY(hipDeviceGetUuid(&id, device));
+        static const char* hex = "0123456789abcdef";
+        for (int i = 0; i < 16; ++i) {
+            uuid_hex[2 * i] = hex[((unsigned char)id.bytes[i]) >> 4];
+            uuid_hex[2 * i + 1] = hex[((unsigned char)id.bytes[i]) & 15];
+        }
+        uuid_hex[32] = 0;
+    }
+    return CF_OK;
+}
+
 extern "C" int cf_abi_version(void) { return CF_ABI_VERSION; }
 extern "C" const char* cf_version(void) { return "catfish_hip 0.3 (gfx950; fp32 MFMA 16x16x4, bf16 / bf16x3 MFMA 32x32x16)"; }

@@ -122,20 +122,33 @@ static int load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 4, std::min<int64_t>(n_files, 64)));
     std::vector<cf_loader::Item> items((size_t)n_files);
     std::vector<int64_t> bad((size_t)nt, -1);                    // first offending file per thread
+    std::vector<int64_t> nomem((size_t)nt, -1);                  // first file whose bytes did not fit host memory, per thread
     cf_loader::run_pool(nt, [&](int t) {
         for (int64_t i = t; i < n_files; i += nt) {              // interleaved: neighbouring files are neighbours on disk
             cf_loader::Item& it = items[(size_t)i];
             bool ok = false;
-            try { ok = cf_loader::slurp(paths + path_bounds[i], it); } catch (...) { ok = false; }    // (bad_alloc: a thread may not throw)
+            try {
+                ok = cf_loader::slurp(paths + path_bounds[i], it);
+            } catch (const std::bad_alloc&) {                   // a thread may not throw: remembered, reported as CF_ERR_NOMEM below
+                ok = false;
+                if (nomem[(size_t)t] < 0) nomem[(size_t)t] = i;
+            } catch (...) {
+                ok = false;
+            }
             if (!ok) {
                 it.count = -1;
                 if (bad[(size_t)t] < 0) bad[(size_t)t] = i;
             }
         }
     });
-    int64_t first_bad = -1;
+    int64_t first_bad = -1, first_nomem = -1;
     for (int64_t b : bad)
         if (b >= 0 && (first_bad < 0 || b < first_bad)) first_bad = b;
+    for (int64_t b : nomem)
+        if (b >= 0 && (first_nomem < 0 || b < first_nomem)) first_nomem = b;
+    // out of memory is not "another kind of file": the caller must not answer it by loading the same bytes again elsewhere
+    if (first_nomem >= 0)
+        return fail(CF_ERR_NOMEM, std::string("cf_load_npy_int16: out of host memory while reading ") + (paths + path_bounds[first_nomem]));
     if (first_bad >= 0)
         return fail(CF_ERR_INVALID, std::string("cf_load_npy_int16: not a readable one-dimensional little-endian int16 .npy: ") +
                                         (paths + path_bounds[first_bad]));

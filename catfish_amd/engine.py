@@ -15,6 +15,14 @@ WINDOW = N.CF_WINDOW
 DEFAULT_MAX_WINDOWS = 32768   # one pass covers 256 reads of 4096 samples (30 208 windows)
 
 
+def device_identity(device):
+    """-> (pci bus id ``"dddd:bb:dd.f"``, uuid as 32 hex digits) of HIP device ``device`` of this process (``cf_device_identity``):
+    which card a rank drives, for ``placement.verify`` and the benchmark line.  Opens the HIP runtime."""
+    bus, uuid = C.create_string_buffer(64), C.create_string_buffer(33)
+    N.check(N.lib().cf_device_identity(int(device), bus, 64, uuid, 33))
+    return bus.value.decode("ascii", "replace").lower(), uuid.value.decode("ascii", "replace")
+
+
 class HipEngine(object):
     """The forward pass of one ResNetRNN checkpoint on one GPU."""
 
@@ -49,6 +57,10 @@ class HipEngine(object):
             self.close()
         except Exception:
             pass
+
+    def device_identity(self):
+        """(pci bus id, uuid hex) of the card this engine drives."""
+        return device_identity(self.device)
 
     @property
     def workspace_bytes(self):

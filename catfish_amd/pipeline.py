@@ -83,6 +83,8 @@ class ReadPipeline(object):
         rc = self.eng._lib.cf_load_npy_int16(blob, bounds.ctypes.data_as(C.c_void_p), len(paths),
                                              C.c_void_p(self.stage[slot].data_ptr()), self.cap,
                                              lengths.ctypes.data_as(C.c_void_p), C.byref(total), int(n_threads))
+        if rc == N.CF_ERR_NOMEM:
+            N.check(rc)         # out of host memory is not "a file of another kind": loading the same bytes again through the general loader would only hide it
         if rc != N.CF_OK:
             return None
         self.k += 1

@@ -125,6 +125,57 @@ def agree_or_raise(error, stage, group=None, token=None):
             stage, ", ".join(str(r) for r in differing), said[differing[0]][1], said[0][1]))
 
 
+def scan_block(input_dir, rank=0, world_size=1):
+    """This rank's share of listing the input directory (catfish/catfish:49-50 lists it once, in one process): the NAMES of all
+    entries, sorted (one readdir pass, no stat) and the sizes on disk of entries ``[lo, hi)`` = this rank's n/world_size block of
+    them -- so a directory of 100 000 reads costs every rank one readdir and 1/world_size of the stats instead of all of them.
+    -> (names, lo, int64 sizes of names[lo:hi])."""
+    names = sorted(os.listdir(input_dir))
+    lo, hi = rank * len(names) // world_size, (rank + 1) * len(names) // world_size
+    fd = os.open(input_dir, os.O_RDONLY | getattr(os, "O_DIRECTORY", 0))
+    try:
+        sizes = np.fromiter((os.stat(n, dir_fd=fd).st_size for n in names[lo:hi]), dtype=np.int64, count=hi - lo)
+    finally:
+        os.close(fd)
+    return names, lo, sizes
+
+
+def agree_on_listing(error, scanned, group=None):
+    """Every rank hands in what ``scan_block`` gave it (or the exception that stopped it, or the one of a step before it) and
+    all of them leave with the same ``(names, sizes)`` over the whole directory -- or all raise: the failing rank its own
+    exception, the others a RuntimeError naming it; and when the ranks saw DIFFERENT sets of names (a file still being copied in,
+    stale attributes of a network file system on one of them) a RuntimeError naming the ranks that differ from rank 0, because
+    blocks cut from differing listings overlap or leave gaps with plausible totals.  One small all-gather (a digest, a count and
+    the block's sizes per rank)."""
+    import hashlib
+    import torch.distributed as dist
+    names = lo = sizes = digest = None
+    if error is None:
+        names, lo, sizes = scanned
+        digest = hashlib.sha1("\0".join(names).encode("utf-8", "surrogateescape")).hexdigest()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if error is not None:
+            raise error
+        return names, [int(s) for s in sizes]
+    said = [None] * dist.get_world_size()
+    mine = (None if error is None else "%s: %s" % (type(error).__name__, error), digest, None if names is None else len(names), lo, sizes)
+    dist.all_gather_object(said, mine, group=group)
+    if error is not None:
+        raise error
+    stage = "listing the input directory"
+    bad = ["rank %d: %s" % (r, t[0]) for r, t in enumerate(said) if t[0] is not None]
+    if bad:
+        raise RuntimeError("%s failed on %s" % (stage, "; ".join(bad)))
+    differing = [r for r, t in enumerate(said) if (t[1], t[2]) != (said[0][1], said[0][2])]
+    if differing:
+        raise RuntimeError("%s: rank(s) %s disagree with rank 0 (%d names, digest %s against %d names, digest %s)" % (
+            stage, ", ".join(str(r) for r in differing), said[differing[0]][2], said[differing[0]][1], said[0][2], said[0][1]))
+    all_sizes = np.concatenate([t[4] for t in said]) if said else np.zeros(0, np.int64)
+    if [t[3] for t in said] != [r * len(names) // len(said) for r in range(len(said))] or len(all_sizes) != len(names):
+        raise RuntimeError("%s: the ranks' blocks do not tile the listing" % stage)
+    return names, [int(s) for s in all_sizes]
+
+
 def host_gather_group():
     """A gloo group for the final host gather (object pickles travel over TCP/shared memory, never
     through RCCL); falls back to the default group when that already is gloo."""

@@ -38,7 +38,7 @@ extern "C" {
 
 /* Bumped whenever a signature or a struct of this header changes; cf_abi_version() returns the value the library was built
  * with, so a binding can refuse a stale libcatfish_hip.so instead of calling it with the wrong arguments. */
-#define CF_ABI_VERSION 4
+#define CF_ABI_VERSION 5
 
 /* Arithmetic of the biGRU layers (the residual blocks, the hidden state, the gates'
  * sigmoid/tanh and all accumulation are fp32 in every mode). */
@@ -327,6 +327,13 @@ const char* cf_profile_slot_name(int slot);
  * = residual block outputs, n_layers_res + l = GRU layer l output (not
  * available for the last layer, whose output only exists as logits). */
 int cf_debug_stage(cf_model* m, int stage, int64_t n_windows, float* out_host);
+
+/* Which card HIP device `device` of this process is -- the reference's per-file loop (catfish/catfish:50-82) shards over one
+ * process per GPU, and each rank binds itself to the host CPUs next to ITS card (catfish_amd/placement.py) and says in the
+ * benchmark line which card it drove.  pci_bus_id (>= 13 bytes, may be NULL) receives "dddd:bb:dd.f", the name of the
+ * device's directory under /sys/bus/pci/devices (upper- or lower-case hex, as the runtime prints it); uuid_hex (>= 33 bytes,
+ * may be NULL) the 16-byte device UUID as 32 hex digits.  Opens the HIP runtime (not a context on the device). */
+int cf_device_identity(int device, char* pci_bus_id, int64_t bus_cap, char* uuid_hex, int64_t uuid_cap);
 
 int64_t cf_workspace_bytes(const cf_model* m);
 const char* cf_last_error(void);

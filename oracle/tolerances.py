@@ -13,4 +13,9 @@ GATE_MAX_ABS_DP = 1e-4                    # fp32 and bf16x3 against the fp64 ora
 
 CONFIG4_MIN_LABEL_MATCH = 0.998           # over all samples of the checked reads, against the fp32 oracle
 CONFIG4_MIN_LABEL_MATCH_PER_READ = 0.99   # no single read may fall below this
-CONFIG4_MAX_ABS_DP = 2e-2                 # max |dp| against the fp32 oracle over all samples of the checked reads
+# max |dp| against the fp32 oracle.  PARITY UNPINNED BY THE REFERENCE: it holds no bf16 fixture and states no bf16 tolerance, so
+# both bounds below are the builder's, set from measurements on the MI355X.  A maximum over samples grows with the number of
+# samples looked at, hence two scales (one loose constant for both let the per-sample check of the test drift):
+CONFIG4_MAX_ABS_DP_TEST = 1e-2            # tests/test_gpu_pipeline.py::test_config4_bf16_packed_varlen: 27 reads <= 16 384 samples,
+                                          # 93 k samples in all, measured 6.9e-3 -- a k-block whose operands went missing lands far above
+CONFIG4_MAX_ABS_DP = 2e-2                 # bench.py's config4 leg: 32 reads spread up to the longest of 10 000 (measured 1.19e-2)

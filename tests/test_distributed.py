@@ -350,15 +350,23 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
     if break_setup == "short":                                             # every pwrite stops after 7 bytes
         real_pwrite = os.pwrite
         os.pwrite = lambda fd, data, offset: real_pwrite(fd, bytes(data[:7]), offset)
-    if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet)
-        import contextlib
-        real_scandir = os.scandir
+    if break_setup == "write-type" and rank == world - 1:                 # not an OSError: the agreement must still be reached
+        from catfish_amd import chunks
 
-        @contextlib.contextmanager
-        def stale(path):
-            with real_scandir(path) as it:
-                yield sorted(it, key=lambda e: e.name)[:-1]
-        os.scandir = stale
+        def wrong_type(fd, data, offset):
+            raise TypeError("a bytes-like object is required, not 'str'")
+        chunks._pwrite_all = wrong_type
+    if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet)
+        real_listdir = os.listdir
+        os.listdir = lambda path=".": sorted(real_listdir(path))[:-1] if str(path).endswith("reads") else real_listdir(path)
+    if break_setup == "count-stats":                                       # every stat of a read through the directory handle is counted
+        real_stat, seen = os.stat, []
+
+        def counting(path, *a, **k):
+            if k.get("dir_fd") is not None:
+                seen.append(path)
+            return real_stat(path, *a, **k)
+        os.stat = counting
     t0 = time.time()
     try:
         res = cli.run_pipeline(os.path.join(tmpdir, "reads"), os.path.join(tmpdir, out_name), chunk_size=300,
@@ -367,6 +375,8 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
         outcome = "returned %d reads, table %s" % (res["reads"], None if table is None else len(table))
     except Exception as exc:                                               # noqa: BLE001 -- recorded for the parent
         outcome = "%s %s" % (type(exc).__name__, exc)
+    if break_setup == "count-stats":
+        outcome += " stats %d" % len(seen)
     open(os.path.join(tmpdir, "%s.rank%d" % (out_name, rank)), "w").write("%.1f %s" % (time.time() - t0, outcome))
 
 
@@ -439,6 +449,37 @@ def test_a_rank_whose_write_fails_fails_the_job_at_once(tmp_path):
 
 
 @pytest.mark.timeout(120)
+def test_a_rank_whose_write_fails_with_any_exception_fails_the_job_at_once(tmp_path):
+    """``stage()`` caught only OSError, so a TypeError / MemoryError out of one rank's write skipped the agreement on
+    that rank and left its peer in the all-gather until the group timed out.  Every exception now goes to the agreement."""
+    import torch.multiprocessing as mp
+    _write_reads(str(tmp_path / "reads"), 6)
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 6, "out", "write-type"), nprocs=2, join=True)
+    r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
+    assert float(r0[0]) < 30 and float(r1[0]) < 30
+    assert r1[1].startswith("TypeError") and "bytes-like" in r1[1]
+    assert r0[1].startswith("RuntimeError") and "writing the chunk documents failed on rank 1: TypeError" in r0[1]
+    assert sorted(os.listdir(tmp_path / "out" / "TEMP")) == ["HP", "nonHP"]
+
+
+@pytest.mark.timeout(120)
+def test_every_rank_stats_only_its_block_of_the_listing(tmp_path):
+    """the listing of the input directory (catfish/catfish:49-50) used to be a scandir + stat of EVERY file on
+    EVERY rank (800 000 stats for 100 000 files on 8 ranks) and was left out of the timed region.  Now a rank reads the names
+    and stats its n/world block; the sizes travel in the agreement.  4 ranks, 10 files: 2 + 3 + 2 + 3 stats, same documents as 1."""
+    import torch.multiprocessing as mp
+    _write_reads(str(tmp_path / "reads"), 10)
+    mp.spawn(_pipeline_worker, args=(4, _free_port(), str(tmp_path), 10, "out4", "count-stats"), nprocs=4, join=True)
+    mp.spawn(_pipeline_worker, args=(1, _free_port(), str(tmp_path), 10, "out1", "count-stats"), nprocs=1, join=True)
+    said = [(tmp_path / ("out4.rank%d" % r)).read_text() for r in range(4)]
+    assert all("returned 10 reads" in t for t in said), said
+    assert [int(t.rsplit(" ", 1)[1]) for t in said] == [2, 3, 2, 3]
+    assert (tmp_path / "out1.rank0").read_text().endswith("stats 10")
+    for f in ("hp_positions.json", "nonhp_positions.json"):
+        assert (tmp_path / "out4" / "TEMP" / f).read_bytes() == (tmp_path / "out1" / "TEMP" / f).read_bytes()
+
+
+@pytest.mark.timeout(120)
 def test_short_writes_are_completed(tmp_path):
     """os.pwrite may write less than it was given; the documents must come out whole (2 ranks against 1, 7 bytes per call)."""
     import torch.multiprocessing as mp
@@ -455,8 +496,8 @@ def test_short_writes_are_completed(tmp_path):
 @pytest.mark.timeout(120)
 def test_ranks_that_list_the_input_directory_differently_fail_at_set_up(tmp_path):
     """every rank cuts its block out of its own listing of the input directory; a rank that sees another
-    listing (a file still being copied in, stale NFS attributes) would silently duplicate or drop reads.  The ranks now
-    compare a digest of (names, sizes) in the set-up exchange."""
+    listing (a file still being copied in, stale NFS attributes) would silently duplicate or drop reads.  The ranks
+    compare a digest of the names in the listing exchange (``sharding.agree_on_listing``; the sizes come from one rank each)."""
     import torch.multiprocessing as mp
     _write_reads(str(tmp_path / "reads"), 6)
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 6, "out", "listing"), nprocs=2, join=True)

@@ -145,8 +145,8 @@ def test_config4_bf16_packed_varlen(ckpt_weights):
     """BASELINE configs[3] as stated: variable-length reads 512..16384 (log-uniform, seed 2) as raw DAC squiggles, in
     length-bucketed PACKED launches, bf16 biGRU arithmetic -- through batching.infer_reads_dac (device normalisation,
     forward pass, device post-processing).  Judged like SURVEY 8d says, by the constants of oracle/tolerances.py that the
-    bench's config4 leg uses too: label match rate against the fp32 oracle over all samples and per read, and the loose
-    bound on max |dp|; edge lengths 512, 16384, 35k and 35k + 1 included."""
+    bench's config4 leg uses too: label match rate against the fp32 oracle over all samples and per read, and a
+    bound on max |dp| at this test's own scale (unpinned by the reference, see tolerances.py); edge lengths 512, 16384, 35k and 35k + 1 included."""
     from catfish_amd import batching
     from catfish_amd.engine import HipEngine
     from oracle import tolerances as tol
@@ -174,7 +174,7 @@ def test_config4_bf16_packed_varlen(ckpt_weights):
         assert spans == (oracle.hp_in_pred(lab) if lab.any() else [])
     print("config 4: label match %.5f over %d samples, max |dp| %.2e" % (n_match / n_tot, n_tot, worst))
     assert n_match / n_tot >= tol.CONFIG4_MIN_LABEL_MATCH
-    assert worst <= tol.CONFIG4_MAX_ABS_DP
+    assert worst <= tol.CONFIG4_MAX_ABS_DP_TEST          # the bound at THIS test's scale (1e-2), not the bench leg's looser one
 
 
 def test_config4_at_scale_is_invariant_to_the_packing(ckpt_weights):

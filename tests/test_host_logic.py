@@ -402,6 +402,46 @@ def test_roofline_is_reported_against_the_nearer_roof():
     assert out["hbm_detail"]["traffic_rate_frac"] > out["frac"]            # 1.5x re-read: each direction reads the whole input
     tie = {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None}
     assert bench.nearer_roof(dict(tie), "bf16", n, 1e-3)["bound"] == "mfma"   # no traffic record, algorithmic bytes below
+    # bf16x3 in profiles/r04_bench_default.json -- issued pipe 0.489, algorithmic HBM 0.354, MEASURED traffic 0.520 of
+    # peak: the measured traffic takes part in the decision again, and a gap under 10 % is reported as a near tie
+    secs = 0.37735e-3
+    x3 = {"bound": "mfma", "achieved": 409.8, "peak": 2500.0, "unit": "TFLOP/s", "frac": 409.8 / 2500.0, "traffic": 0.520 * 8e12 * secs}
+    out = bench.nearer_roof(dict(x3), "bf16x3", n, secs)
+    assert out["bound"] == "hbm" and out["near_tie"] is True and "measured HBM traffic" in out["decided_by"] and "near tie" in out["decided_by"]
+    assert abs(out["hbm_detail"]["traffic_rate_frac"] - 0.520) < 1e-6 and abs(out["matrix_pipe_issued"]["frac"] - 3 * 409.8 / 2500.0) < 1e-9
+    assert abs(out["frac"] - 1024 * n / secs / 8e12) < 1e-9                  # frac / achieved stay algorithmic
+    out = bench.nearer_roof(dict(x3, traffic=None), "bf16x3", n, secs)        # without the record: issued pipe 0.49 against 0.35
+    assert out["bound"] == "mfma" and out["near_tie"] is False and "ISSUED matrix-pipe" in out["decided_by"]
+
+
+def test_build_records_kernel_resources_and_no_kernel_spills():
+    """gru_bf16x3_pipe_kernel is built around the whole 512-register file of a one-wave-per-SIMD launch; nothing
+    recorded that its four instantiations compile without scratch.  catfish_amd/build.py now parses hipcc's
+    -Rpass-analysis=kernel-resource-usage remarks into csrc/kernel_resources.json and refuses a build whose kernels spill."""
+    import json
+    from catfish_amd import build
+    text = ("x.hip:9:1: remark: Function Name: _Z1kv [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     TotalSGPRs: 44 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     AGPRs: 124 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     ScratchSize [bytes/lane]: 16 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     Occupancy [waves/SIMD]: 1 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     VGPRs Spill: 4 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hip:9:1: remark:     LDS Size [bytes/block]: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    got = build.parse_resource_remarks(text)
+    assert got == {"_Z1kv": {"sgprs": 44, "vgprs": 256, "agprs": 124, "scratch_bytes_per_lane": 16, "waves_per_simd": 1,
+                             "vgpr_spills": 4, "lds_bytes": 0}}
+    assert build.check_resources(got) and "scratch 16" in build.check_resources(got)[0]
+    assert build.check_resources({"k": {"vgprs": 256, "agprs": 257, "scratch_bytes_per_lane": 0}})
+    if not os.path.exists(build.RESOURCES):
+        pytest.skip("library not built here")
+    with open(build.RESOURCES) as fh:
+        rec = json.load(fh)
+    kernels = rec["kernels"]
+    assert len(kernels) >= 70 and build.check_resources(kernels) == []
+    x3 = {k: v for k, v in kernels.items() if "gru_bf16x3_pipe_kernel" in k}
+    assert len(x3) == 4 and all(v["waves_per_simd"] == 1 and v["scratch_bytes_per_lane"] == 0 and 256 < v["vgprs"] + v["agprs"] <= 512
+                                for v in x3.values())
 
 
 def test_native_npy_loader_reads_what_the_python_loader_reads(tmp_path):

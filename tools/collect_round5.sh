@@ -1,0 +1,31 @@
+#!/bin/bash
+# GPU box: the round-5 measurements the docs cite, written under gpurun_out/round5/ (copy what is judged into profiles/).
+# usage:  bash tools/collect_round5.sh <commit> [stage ...]     stages: probe tests bench rehearse prof (default: all)
+COMMIT=${1:-unknown}; shift
+STAGES=${@:-probe tests bench rehearse prof}
+ROOT="$GRAFT_REPO_ROOT"
+OUT="$ROOT/gpurun_out/round5"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+echo "commit $COMMIT stages $STAGES" > $OUT/commit.txt
+for S in $STAGES; do
+  case $S in
+    probe) bash tools/probe_sysfs.sh > $OUT/sysfs_probe.log 2>&1 ;;
+    tests) timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1 || { echo "gpu tests FAILED" >> $OUT/commit.txt; tail -30 $OUT/gpu_tests.log; exit 1; } ;;
+    bench) timeout -k 10 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo "bench FAILED" >> $OUT/commit.txt; tail -20 $OUT/bench_default.err; exit 1; } ;;
+    rehearse)
+      for N in 2 4; do
+        CATFISH_BENCH_DEVICE=0 CATFISH_DEVICE=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
+          --master-port $((29500 + N)) bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_${N}ranks_one_gpu.json 2> $OUT/bench_${N}ranks.err \
+          || { echo "rehearsal $N FAILED" >> $OUT/commit.txt; tail -20 $OUT/bench_${N}ranks.err; exit 1; }
+      done ;;
+    prof)
+      for P in fp32 bf16 bf16x3; do
+        rm -rf /tmp/kt_$P
+        rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$P -o kt -- python3 bench.py --precision $P --no-cpu-baseline --no-extra-precisions --no-sharded-leg > $OUT/bench_prof_$P.json 2>/dev/null
+        cp $(find /tmp/kt_$P -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_$P.csv
+      done ;;
+  esac
+  echo "$S done" >> $OUT/commit.txt
+done
+echo "all done" >> $OUT/commit.txt
