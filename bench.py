@@ -48,6 +48,17 @@ CONFIG4_PARITY_READS = 32           # reads of it checked against the fp32 oracl
 RANK_NOTES = {}                     # what this rank's informational legs want in its entry of the line's ``ranks`` list
 
 
+_T_START = time.perf_counter()
+
+
+def progress(what):
+    """One line on stderr per stage (never stdout: that carries the ONE JSON line): a long run shows where it is, and a hung one
+    shows where it stopped.  ``CATFISH_BENCH_WATCHDOG_S=N`` additionally dumps every thread's Python stack to stderr every N
+    seconds (faulthandler), which names the call a hang sits in."""
+    sys.stderr.write("bench.py [%7.1f s] rank %s: %s\n" % (time.perf_counter() - _T_START, os.environ.get("RANK", "0"), what))
+    sys.stderr.flush()
+
+
 def squiggle_dac(rng, length):
     """One seeded synthetic read: int16 DAC squiggle of SURVEY 8d (levels N(500,60^2), dwell Geometric(1/9),
     noise N(0,8^2), clipped to [0,2047])."""
@@ -332,7 +343,7 @@ def leg_config5(weights, local_rank, torch):
                                                 "what": "whole training step (not one kernel): 3 x forward FLOPs per window (389 504 x 35) / step "
                                                         "time / fp32 MFMA peak"
                                                         + ("; at the reference's batch of 256 windows the step is ~30 dependent launches of 16 "
-                                                           "tiles each -- latency-bound, 6 % of the chip's workgroup slots" if batch == 256 else "")}}
+                                                           "tiles each -- latency-bound, 16 tiles for 256 CUs" if batch == 256 else "")}}
         if batch == 256:
             gpu = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=1.0, device=dev, seed=0)
             cpu = Trainer(weights, 3, 2, "Adam", 1e-3, keep_prob=1.0, device="cpu", seed=0)
@@ -530,6 +541,9 @@ def main():
         print(json.dumps(leg_config4(load_weights(), 0, torch, profile_only=True)))
         return
 
+    if os.environ.get("CATFISH_BENCH_WATCHDOG_S"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CATFISH_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     launcher_local_rank = local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -539,6 +553,7 @@ def main():
         shared_device = local_rank = int(os.environ["CATFISH_BENCH_DEVICE"])
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("cpu_baseline leg (oracle on the host cores)")
         cpu_res = cpu_baseline()
 
     # Rank placement BEFORE the first GPU call and the first pinned allocation: this rank (and the loader thread, the library's
@@ -548,8 +563,13 @@ def main():
     place = placement.bind(launcher_local_rank, local_world,
                            device_of_rank=(lambda r: shared_device) if shared_device is not None else None)
 
+    progress("bound to CPUs %s (%s); importing torch" % (placement.format_cpulist(place.get("cpus") or []), place.get("source")))
     import torch
     import torch.distributed as dist
+    # The rank now owns fewer CPUs than the machine has, but OpenMP sized its pool when it was first loaded (numpy, above): a
+    # pool of 256 spinning threads on 128 CPUs turned the torch-CPU CHECKER of the config5 leg from 3 s into 266 s (measured,
+    # gpurun_out/round5 first run).  One thread per owned CPU at most; the product path runs no torch CPU op at all.
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(place.get("cpus") or [1]), 64)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
@@ -576,11 +596,13 @@ def main():
             dist.all_reduce(probe)
             backend, ranks_seen = "gloo", int(round(float(probe.item())))
 
+    progress("process group %s; creating the engine on device %d" % (backend, local_rank))
     from catfish_amd.engine import HipEngine
     weights = load_weights()
     eng = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, n_streams=args.streams,
                     precision=args.precision)
     pci_bus_id, uuid = eng.device_identity()
+    progress("engine on %s; generating %d reads" % (pci_bus_id, args.pool_reads))
     placement.verify(place, pci_bus_id, launcher_local_rank, local_world)     # the card the runtime gave us against the sysfs guess
 
     # every rank owns its own shard of reads (seeded by rank): no data-path collective
@@ -596,6 +618,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    progress("warm-up and the timed steps")
     warm_by_time(eng, batches, outs, args.prewarm_ms * 1e-3, torch)      # clock warm-up, outside the W + K steps
     for i in range(args.warmup):
         eng.infer_device(batches[i % n_batches], out=outs[i & 1])
@@ -627,6 +650,7 @@ def main():
 
     result = None
     parity_ok = True
+    progress("timed region done: %.3f ms per step; parity gate" % (dt / args.steps * 1e3))
     if rank == 0:
         # parity gate of the benchmarked configuration against the oracle (not timed): a build that fails it reports no value
         from oracle import catfish_oracle as oracle
@@ -675,6 +699,7 @@ def main():
         for prec in ("fp32", "bf16x3", "bf16"):
             if prec == args.precision:
                 continue
+            progress("other_precisions leg: %s" % prec)
             e2 = HipEngine(weights, device=local_rank, max_windows_per_pass=READS_PER_STEP * 118, precision=prec)
             warm_by_time(e2, batches, outs, 0.5, torch)      # the GPU clocks down while the CPU oracle ran
             n2 = max(5, args.steps // 2)
@@ -695,14 +720,17 @@ def main():
                            "kernels_ms": {k: v[0] / v[1] for k, v in k2.items()}}
             e2.close()
         result["other_precisions"] = extra
+        progress("config4 leg (10 000 variable-length reads, bf16)")
         result["config4"] = leg_config4(weights, local_rank, torch)
         for name, leg in (("latency", lambda: leg_latency(eng, torch, local_rank)),
                           ("config5", lambda: leg_config5(weights, local_rank, torch))):
+            progress("%s leg" % name)
             try:
                 result[name] = leg()
             except Exception as exc:      # informational legs: never lose the headline line to them
                 result[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         # informational: host-to-host rate of the streaming pipeline (pinned int16 DAC in, spans out, PCIe inclusive)
+        progress("host_to_host_pipeline leg")
         from catfish_amd.pipeline import ReadPipeline
         _, dacs = make_reads(READS_PER_STEP, seed=77, return_dac=True)
         pipe = ReadPipeline(eng, max_samples_per_batch=READS_PER_STEP * READ_LEN)
@@ -719,6 +747,7 @@ def main():
                                            "what": "pinned int16 DAC -> cf_normalize -> cf_infer -> cf_postprocess -> cf_spans -> "
                                                    "host span table, double-buffered; never the headline value"}
     if not args.no_sharded_leg and args.precision == "fp32":
+        progress("sharded_gather leg (%d reads per rank)" % SHARDED_READS_PER_RANK)
         try:
             sg = leg_sharded_gather(eng, weights, rank, world, dist, torch)
         except Exception as exc:      # informational leg: never lose the headline line to it
@@ -729,6 +758,7 @@ def main():
             result["sharded_gather"] = sg
     eng.close()
     if not args.no_sharded_leg and args.precision == "fp32":
+        progress("cli_end_to_end leg (%d files per rank)" % SHARDED_READS_PER_RANK)
         try:
             ce = leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch)
         except Exception as exc:      # informational leg: never lose the headline line to it
@@ -740,6 +770,7 @@ def main():
     # Who ran what where: every rank's identity, placement and times, gathered over the HOST group (gloo) and printed by rank 0,
     # so that a scaling record can be judged from the line alone -- did the collective see N ranks, did every rank drive its own
     # card, which rank was the slow one.  Ranks that SHARE a card are a rehearsal of the launch path, not a measurement.
+    progress("legs done; gathering the ranks' records")
     import socket
     me = {"rank": rank, "local_rank": launcher_local_rank, "device_index": local_rank, "pci_bus_id": pci_bus_id, "uuid": uuid,
           "device_name": torch.cuda.get_device_name(local_rank), "host": socket.gethostname(), "pid": os.getpid(),

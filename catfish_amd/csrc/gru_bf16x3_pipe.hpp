@@ -37,7 +37,8 @@
 #ifndef CF_X3_STAMP
 #define CF_X3_STAMP 0
 #endif
-// Timing-only ablation (results are WRONG when set): bit 0 = no vector work, bit 1 = no MFMAs
+// Timing-only ablation (results are WRONG when set): bit 0 = no vector work, bit 1 = no MFMAs, bit 2 = no A-ring refills (the three
+// fragments of the prologue are reused for every product: the upper bound of what holding weight fragments in registers could save)
 #ifndef CF_X3_ABL
 #define CF_X3_ABL 0
 #endif
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256, 1) void gru_bf16x3_pipe_kernel(const char* __r
             else if constexpr (opens) acc[d.mt] = MFMA32B(a, b, bias[d.mt]);
             else acc[d.mt] = MFMA32B(a, b, acc[d.mt]);
             // the hi fragment is dead after the second MFMA, the lo fragment after the third
-            if constexpr (sub == 1 && !(FINAL && p + DA >= G::OC)) ar[p % DA][0] = WAF[(G::prod((p + DA) % NSEQ).frag * 2 + 0) * 64];
-            if constexpr (sub == 2 && !(FINAL && p + DA >= G::OC)) ar[p % DA][1] = WAF[(G::prod((p + DA) % NSEQ).frag * 2 + 1) * 64];
+            if constexpr (sub == 1 && !(FINAL && p + DA >= G::OC) && !(CF_X3_ABL & 4)) ar[p % DA][0] = WAF[(G::prod((p + DA) % NSEQ).frag * 2 + 0) * 64];
+            if constexpr (sub == 2 && !(FINAL && p + DA >= G::OC) && !(CF_X3_ABL & 4)) ar[p % DA][1] = WAF[(G::prod((p + DA) % NSEQ).frag * 2 + 1) * 64];
         };
         // vector micro-op q of gap g (x3::make_sched decides which)
         auto vop = [&](auto g_, auto q_, auto final_, bf16x8 (&xa)[KBX][2], bf16x8 (&xb)[KBX][2], int s, int t) __attribute__((always_inline)) {

@@ -7,6 +7,8 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <cerrno>
+#include <cstring>
 #include <thread>
 #include <new>
 #include <stdexcept>
@@ -177,5 +179,51 @@ extern "C" int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, 
         return fail(CF_ERR_NOMEM, "cf_load_npy_int16: out of host memory");
     } catch (const std::exception& e) {
         return fail(CF_ERR_INVALID, std::string("cf_load_npy_int16: ") + e.what());
+    }
+}
+
+// Sizes on disk of many entries of ONE directory (the listing of the reference's per-file loop, catfish/catfish:49-50, needs them to
+// cut the file list into blocks of equal work and into batches before anything is read): fstatat relative to one directory handle
+// from a small pool of threads, each a contiguous block of the names -- 12 500 entries cost a Python loop of os.stat 19 ms, this 3-5.
+static int stat_files(const char* dir, const char* names, const int64_t* name_bounds, int64_t n_files, int64_t* sizes, int32_t n_threads) {
+    if (n_files < 0) return fail(CF_ERR_INVALID, "cf_stat_files: negative count");
+    if (n_files == 0) return CF_OK;
+    if (!dir || !names || !name_bounds || !sizes) return fail(CF_ERR_INVALID, "cf_stat_files: null buffer");
+    const int dfd = open(dir, O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+    if (dfd < 0) return fail(CF_ERR_INVALID, std::string("cf_stat_files: cannot open directory ") + dir + ": " + strerror(errno));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 4, std::min<int64_t>((n_files + 255) / 256, 64)));
+    std::vector<int64_t> bad((size_t)nt, -1);
+    std::vector<int> bad_errno((size_t)nt, 0);
+    try {
+        cf_loader::run_pool(nt, [&](int t) {
+            const int64_t lo = n_files * t / nt, hi = n_files * (t + 1) / nt;
+            for (int64_t i = lo; i < hi; ++i) {
+                struct stat st;
+                if (fstatat(dfd, names + name_bounds[i], &st, 0) == 0) sizes[i] = (int64_t)st.st_size;
+                else {
+                    sizes[i] = -1;
+                    if (bad[(size_t)t] < 0) { bad[(size_t)t] = i; bad_errno[(size_t)t] = errno; }
+                }
+            }
+        });
+    } catch (...) {
+        close(dfd);
+        throw;
+    }
+    close(dfd);
+    for (int t = 0; t < nt; ++t)
+        if (bad[(size_t)t] >= 0)
+            return fail(CF_ERR_INVALID, std::string("cf_stat_files: ") + dir + "/" + (names + name_bounds[bad[(size_t)t]]) + ": " +
+                                            strerror(bad_errno[(size_t)t]));
+    return CF_OK;
+}
+
+extern "C" int cf_stat_files(const char* dir, const char* names, const int64_t* name_bounds, int64_t n_files, int64_t* sizes, int32_t n_threads) {
+    try {
+        return stat_files(dir, names, name_bounds, n_files, sizes, n_threads);
+    } catch (const std::bad_alloc&) {
+        return fail(CF_ERR_NOMEM, "cf_stat_files: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(CF_ERR_INVALID, std::string("cf_stat_files: ") + e.what());
     }
 }

@@ -128,16 +128,29 @@ def agree_or_raise(error, stage, group=None, token=None):
 def scan_block(input_dir, rank=0, world_size=1):
     """This rank's share of listing the input directory (catfish/catfish:49-50 lists it once, in one process): the NAMES of all
     entries, sorted (one readdir pass, no stat) and the sizes on disk of entries ``[lo, hi)`` = this rank's n/world_size block of
-    them -- so a directory of 100 000 reads costs every rank one readdir and 1/world_size of the stats instead of all of them.
-    -> (names, lo, int64 sizes of names[lo:hi])."""
+    them (``stat_sizes``: natively, from a few threads) -- so a directory of 100 000 reads costs every rank one readdir and
+    1/world_size of the stats instead of all of them.  -> (names, lo, int64 sizes of names[lo:hi])."""
     names = sorted(os.listdir(input_dir))
     lo, hi = rank * len(names) // world_size, (rank + 1) * len(names) // world_size
-    fd = os.open(input_dir, os.O_RDONLY | getattr(os, "O_DIRECTORY", 0))
-    try:
-        sizes = np.fromiter((os.stat(n, dir_fd=fd).st_size for n in names[lo:hi]), dtype=np.int64, count=hi - lo)
-    finally:
-        os.close(fd)
-    return names, lo, sizes
+    return names, lo, stat_sizes(input_dir, names[lo:hi])
+
+
+def stat_sizes(directory, names, n_threads=4):
+    """Sizes on disk of ``names`` (entries of ``directory``) as int64 -- ``cf_stat_files``: fstatat from the library's host thread
+    pool (a Python loop of os.stat costs 1.5 us per file, 19 ms for a rank's 12 500 reads; this 3-5 ms).  A name that cannot be
+    stat-ed raises ValueError naming it."""
+    import ctypes as C
+    from . import _native as N
+    sizes = np.empty(len(names), dtype=np.int64)
+    if not names:
+        return sizes
+    enc = [os.fsencode(n) for n in names]
+    blob = b"\x00".join(enc) + b"\x00"
+    bounds = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum(np.fromiter((len(e) + 1 for e in enc), dtype=np.int64, count=len(enc)), out=bounds[1:])
+    N.check(N.lib().cf_stat_files(os.fsencode(directory), blob, bounds.ctypes.data_as(C.c_void_p), len(enc),
+                                  sizes.ctypes.data_as(C.c_void_p), int(n_threads)))
+    return sizes
 
 
 def agree_on_listing(error, scanned, group=None):

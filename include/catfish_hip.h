@@ -210,6 +210,14 @@ int64_t cf_chunks_json(const char* keys, const int64_t* key_bounds, int64_t n_re
 int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
                       int64_t* lengths, int64_t* total, int32_t n_threads);
 
+/* Sizes on disk of n_files entries of ONE directory (host code, no device work): the listing step of the reference's per-file
+ * loop (catfish/catfish:49-50) -- the sizes cut the sorted file list into blocks of equal work per rank and into batches before
+ * anything is read.  names: the entry names (relative to dir) as NUL-terminated strings back to back, name_bounds[n_files + 1]
+ * their byte offsets; sizes[n_files] receives st_size (regular files, and whatever else the directory holds: it is judged when
+ * its turn to be read comes).  fstatat relative to one directory handle from n_threads host threads (<= 0: 4).  CF_ERR_INVALID
+ * names the first entry that cannot be stat-ed (e.g. removed since the listing) in cf_last_error(). */
+int cf_stat_files(const char* dir, const char* names, const int64_t* name_bounds, int64_t n_files, int64_t* sizes, int32_t n_threads);
+
 /* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
  * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,
  * on device buffers in the kernels' fragment layout [tile][t][mtile][lane][4] (tile = 16 windows; element

@@ -8,6 +8,8 @@ child process with the sanitizer runtime preloaded; not collected by pytest itse
   directories and missing paths -- into exactly-sized buffers.  Judge: numpy's own reader.
 * cf_chunks_from_spans / cf_chunks_json (chunks_host.hpp) write into caller-sized buffers: exact, minimum and too-small
   capacities.  Judge: the per-read Python rules (catfish_amd.cli.chunks_of_read) and json.dumps.
+* cf_stat_files (loader_host.hpp) writes one size per name from several threads: files, empty files, directories, missing entries,
+  zero to 700 names.  Judge: os.stat.
 A sanitizer report aborts the process (non-zero exit); a wrong answer raises.
 """
 import ctypes as C
@@ -31,6 +33,8 @@ lib.cf_chunks_from_spans.restype = C.c_int
 lib.cf_chunks_from_spans.argtypes = [P64, P64, P64, P64, C.c_int64, C.c_int64, P64, P64, P64, C.c_int64, P64, P64, P64, C.c_int64]
 lib.cf_chunks_json.restype = C.c_int64
 lib.cf_chunks_json.argtypes = [C.c_char_p, P64, C.c_int64, P64, P64, P64, P8, C.c_char_p, C.c_int64]
+lib.cf_stat_files.restype = C.c_int
+lib.cf_stat_files.argtypes = [C.c_char_p, C.c_char_p, P64, C.c_int64, P64, C.c_int32]
 CF_OK, CF_ERR_INVALID = 0, -1
 SETTINGS = dict(deadline=None, database=None, suppress_health_check=list(HealthCheck))
 
@@ -233,6 +237,44 @@ def fuzz_chunks(reads, chunk_size, room):
                 assert buf.raw[:n] == text
 
 
+# ------------------------------------------------------------------------------------------------ cf_stat_files
+@settings(max_examples=max(20, int(os.environ.get("FUZZ_EXAMPLES", 250)) // 5), **SETTINGS)
+@given(st.lists(st.tuples(st.sampled_from(["file", "file", "file", "empty", "dir", "missing"]), st.integers(0, 5000)), min_size=0, max_size=700),
+       st.integers(-1, 9))
+def fuzz_stat(entries, n_threads):
+    """Sizes of directory entries into an exactly-sized table, from 1..9 threads (blocks of 256 names per thread at most); a missing
+    entry is an error that names it.  Judge: os.stat."""
+    import shutil
+    import tempfile
+    box = tempfile.mkdtemp(dir=SCRATCH)
+    try:
+        names = []
+        for i, (kind, size) in enumerate(entries):
+            name = "e%04d %s.npy" % (i, "\u00e9" if i % 3 == 0 else "x")
+            path = os.path.join(box, name)
+            if kind == "file":
+                with open(path, "wb") as fh:
+                    fh.write(b"\x00" * size)
+            elif kind == "empty":
+                open(path, "wb").close()
+            elif kind == "dir":
+                os.makedirs(path)
+            names.append(name)
+        enc = [os.fsencode(n) for n in names]
+        blob = b"\x00".join(enc) + b"\x00"
+        bounds = arr64(list(np.cumsum([0] + [len(e) + 1 for e in enc])))
+        sizes = (C.c_int64 * max(len(names), 1))()
+        rc = lib.cf_stat_files(os.fsencode(box), blob, bounds, len(names), sizes, n_threads)
+        missing = [n for n, (kind, _s) in zip(names, entries) if kind == "missing"]
+        if missing:
+            assert rc == CF_ERR_INVALID and any(os.fsencode(m) in lib.cf_last_error() for m in missing), lib.cf_last_error()
+        else:
+            assert rc == CF_OK, lib.cf_last_error()
+            assert list(sizes)[:len(names)] == [os.stat(os.path.join(box, n)).st_size for n in names]
+    finally:
+        shutil.rmtree(box, ignore_errors=True)
+
+
 def bad_arguments():
     """NULL tables, negative sizes, descending bounds: an error code, never a fault."""
     z = arr64([0, 0])
@@ -248,10 +290,16 @@ def bad_arguments():
     assert lib.cf_chunks_json(b'"a"', arr64([3, 0]), 1, arr64([0, 1]), one, one, None, buf, 8) == CF_ERR_INVALID            # negative key length
     assert lib.cf_chunks_json(b'"a"', arr64([0, 3]), 1, arr64([0, 1]), None, None, None, buf, 8) == CF_ERR_INVALID          # rows without tables
     assert lib.cf_chunks_json(None, z, 0, z, None, None, None, buf, -1) == CF_ERR_INVALID
+    assert lib.cf_stat_files(None, None, None, 0, None, 1) == CF_OK
+    assert lib.cf_stat_files(None, None, None, 2, None, 1) == CF_ERR_INVALID
+    assert lib.cf_stat_files(b".", b"x\x00", z, -1, z, 1) == CF_ERR_INVALID
+    assert lib.cf_stat_files(os.fsencode(os.path.join(SCRATCH, "no such directory")), b"x\x00", z, 1, arr64([0]), 1) == CF_ERR_INVALID
+    assert b"no such directory" in lib.cf_last_error()
 
 
 if __name__ == "__main__":
     bad_arguments()
     fuzz_loader()
     fuzz_chunks()
+    fuzz_stat()
     print("fuzz ok")

@@ -359,14 +359,13 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
     if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet)
         real_listdir = os.listdir
         os.listdir = lambda path=".": sorted(real_listdir(path))[:-1] if str(path).endswith("reads") else real_listdir(path)
-    if break_setup == "count-stats":                                       # every stat of a read through the directory handle is counted
-        real_stat, seen = os.stat, []
+    if break_setup == "count-stats":                                       # every name handed to the native stat is counted
+        real_sizes, seen = sharding.stat_sizes, []
 
-        def counting(path, *a, **k):
-            if k.get("dir_fd") is not None:
-                seen.append(path)
-            return real_stat(path, *a, **k)
-        os.stat = counting
+        def counting(directory, names, *a, **k):
+            seen.extend(names)
+            return real_sizes(directory, names, *a, **k)
+        sharding.stat_sizes = counting
     t0 = time.time()
     try:
         res = cli.run_pipeline(os.path.join(tmpdir, "reads"), os.path.join(tmpdir, out_name), chunk_size=300,

@@ -490,7 +490,9 @@ def test_bf16x3_pipelined_kernel_agrees_with_unpipelined(ckpt_weights, monkeypat
     against gru_layer_bf16_kernel<.,.,2> (CATFISH_BF16_PIPE=0 behind the debug switch).  Same products in the same order per
     accumulator, same activation arithmetic -- but not the same bits: the round-1 kernel leaves the lo part of r*h to the
     compiler, which contracts most (not all) of its `r*h - hi` into an fma, while the pipelined kernel pins every operation.
-    That moves single bf16 lo parts by one ulp (2^-17 of the value).  So: the two agree to 4e-6 in probability at every call
+    That moves single bf16 lo parts by one ulp (2^-17 of the value).  The ISA of both is kept in
+    profiles/r05_x3_contraction_isa.txt: 11 v_pk_fma_f32 with neg_lo/neg_hi on the addend + 2 v_fma_f32 ..., -v in the round-1
+    kernel (24 of a lane's 32 r*h values per step), none in the pipelined one (v_mul_f32, v_cvt_pk_bf16_f32, v_sub_f32).  So: the two agree to 4e-6 in probability at every call
     size -- one ragged tile, a few tiles, fewer tiles than waves, the benchmark's launch +- a ragged tile, a multi-round
     launch (a lost or stale lo fragment anywhere shows as >= 1e-4) -- and each stays inside the 1e-4 gate of the fp64 oracle."""
     from catfish_amd.engine import HipEngine

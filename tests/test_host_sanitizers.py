@@ -1,6 +1,6 @@
 """AddressSanitizer + UBSan build of the host-only C-ABI entry points (the one optional aux item).
 
-``cf_load_npy_int16`` parses file headers nobody vouches for and ``cf_chunks_from_spans`` / ``cf_chunks_json`` write into
+``cf_load_npy_int16`` parses file headers nobody vouches for, ``cf_stat_files`` fills a size table from several threads and ``cf_chunks_from_spans`` / ``cf_chunks_json`` write into
 caller-sized buffers (catfish_amd/csrc/loader_host.hpp, chunks_host.hpp: plain host code, no device).  They are compiled here
 on their own (tests/native/host_entry_shim.cpp) with ``g++ -fsanitize=address,undefined`` and fuzzed with hypothesis in a child
 process that preloads the sanitizer runtime (tests/native/fuzz_host_entries.py).  CPU only: GPU sanitizers are not available on

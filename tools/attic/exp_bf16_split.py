@@ -1,14 +1,14 @@
 """bf16 forward pass of one 256-read batch as 1, 2, 4 launches of the whole layer stack (smaller launches keep a layer's output
 inside the 256 MB Infinity Cache until the next layer has read it; they also fill the chip less)."""
 import json, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from catfish_amd.engine import HipEngine
 import numpy as np
 
 
 def main():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     with np.load(os.path.join(root, "tests", "golden", "ckpnt-30000-inference.npz")) as z:
         w = {k: z[k] for k in z.files}
     for prec in ("bf16", "fp32"):

@@ -1,6 +1,6 @@
 """Experiment: fused (one launch, dynamic queues) vs per-layer GRU launches at several batch sizes."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from catfish_amd.engine import HipEngine

@@ -1,7 +1,7 @@
 """Experiment: alternate full batches over E engines on E torch streams (tail overlap across steps)."""
 import os, sys, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from catfish_amd.engine import HipEngine

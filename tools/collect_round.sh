@@ -29,7 +29,7 @@ python tools/bench_latency.py > $OUT/latency.json 2>/dev/null
 python tools/bench_train.py > $OUT/train_256.json 2>/dev/null
 python tools/bench_train.py --batch 4096 > $OUT/train_4096.json 2>/dev/null
 python tools/bench_e2e.py > $OUT/e2e.log 2>/dev/null
-python tools/bench_varlen.py --reads 2048 > $OUT/varlen_bf16.json 2>/dev/null
+python tools/attic/bench_varlen.py --reads 2048 > $OUT/varlen_bf16.json 2>/dev/null
 rm -rf /tmp/kt_gen
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_gen -o kt -- python3 tools/bench_generic.py > $OUT/any_size_path.jsonl 2>/dev/null
 cp $(find /tmp/kt_gen -name "*kernel_stats.csv" | head -1) $OUT/any_size_kernel_stats.csv
