@@ -83,12 +83,14 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
     the (sorted) file list on its own MI355X, merges / centres / complements the spans (``sharding.chunk_files_local``),
     formats its part of the two JSON documents and writes it at its offset (``chunks.write_json_documents``).  The ranks
     exchange three small objects over a gloo group -- set-up status, shard status, byte counts -- and no results at all;
-    rank 0 does nothing that grows with the number of ranks.  Files are taken in sorted order (the reference iterates in
-    ``os.listdir`` order, which is arbitrary), so N ranks write the same bytes as one.
+    rank 0 does nothing that grows with the number of ranks.  Files are taken in sorted (bytewise) order (the reference iterates
+    in ``os.listdir`` order, which is arbitrary), so N ranks write the same bytes as one.
 
-    Returns on every rank the totals ``dict(reads, samples, reads_with_hp, hp_chunks, bytes, files)``; with
-    ``gather_table=True`` rank 0's dict also holds ``table``: the ``chunks.ChunkTable`` over all files gathered from the
-    ranks (``table.to_dicts(files)`` = the reference's ``hp_dict`` / ``nonhp_dict``).  ``timings`` (optional dict) receives
+    Returns on every rank the totals ``dict(reads, samples, reads_with_hp, hp_chunks, bytes)`` plus ``files`` / ``file_range``: the
+    names of the files THIS rank classified and their index range in the agreed order of the directory (the whole list is never
+    built as Python strings: ``sharding.DirListing``).  With ``gather_table=True`` rank 0's dict also holds ``table``, the
+    ``chunks.ChunkTable`` over all files gathered from the ranks, and its ``files`` are all names
+    (``table.to_dicts(files)`` = the reference's ``hp_dict`` / ``nonhp_dict``).  ``timings`` (optional dict) receives
     this rank's ``listing_s`` (output directories, the directory listing and the ranks' agreement on it), ``model_s`` (network
     load up to the ranks' agreement on it), ``setup_s`` (their sum), ``infer_s``, ``chunks_s``, ``write_s`` and ``placement``
     (the CPUs the rank bound itself to, ``placement.summary``).
@@ -123,14 +125,14 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
             scanned = sharding.scan_block(input_dir, rank, world)
         except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
             listing_error = exc
-        input_files, file_sizes = sharding.agree_on_listing(listing_error, scanned, group=host_group)
+        listing, file_sizes = sharding.agree_on_listing(listing_error, scanned, group=host_group)
         timings["listing_s"] = time.perf_counter() - t_list
         # 2. the network (catfish/catfish:40-47), outside what the benchmark counts (``model_s``, up to the ranks' agreement on it)
         t_model = time.perf_counter()
         model = setup_error = None
         # Big jobs run 131 072 windows per launch (~1100 reads of 4096 samples): the biGRU launches then end in a 1-2 %
         # tail instead of 8 % and the three layers go out as one dynamically scheduled launch.
-        max_windows = 131072 if len(input_files) > 400 * world else 32768
+        max_windows = 131072 if len(listing) > 400 * world else 32768
         try:
             model = neural_network.load_network(network_type, network_path, checkpoint=checkpoint,
                                                 device=_pick_device(local_rank) if device is None else device,
@@ -149,7 +151,8 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         t2 = datetime.datetime.now()
         mine = table = shard_error = None
         try:
-            mine, table = sharding.chunk_files_local(model, ["{}/{}".format(input_dir, f) for f in input_files], chunk_size,
+            # path strings are built for this rank's block only (sharding.ListingPaths): 100 000 of them on each of 8 ranks was 15 ms
+            mine, table = sharding.chunk_files_local(model, sharding.ListingPaths(listing), chunk_size,
                                                      max_samples_per_batch=max_windows * infer.WINDOW_SIZE, rank=rank,
                                                      world_size=world, timings=timings, file_sizes=file_sizes)
         except Exception as exc:                          # noqa: BLE001 -- a bad file on one rank fails the whole job, at once
@@ -159,9 +162,10 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
             print("Finished determining possible HP stretches in {}".format(datetime.datetime.now() - t2))
             print("Splitting reads...")
         t3 = time.perf_counter()
-        result = chunks.write_json_documents(temp_dir, table, [input_files[i] for i in mine], group=host_group)
+        my_files = listing.names(mine[0], mine[-1] + 1) if mine else []
+        result = chunks.write_json_documents(temp_dir, table, my_files, group=host_group)
         timings["write_s"] = time.perf_counter() - t3
-        result["files"] = input_files
+        result["files"], result["file_range"] = my_files, ((mine[0], mine[-1] + 1) if mine else (0, 0))
         if rank == 0:
             print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
                 temp_dir, datetime.timedelta(seconds=timings["write_s"])))
@@ -173,6 +177,7 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
                 table = chunks.ChunkTable.concat(parts) if rank == 0 else None
             if rank == 0:
                 result["table"] = table
+                result["files"], result["file_range"] = listing.names(), (0, len(listing))
         finished = True
         return result
     finally:

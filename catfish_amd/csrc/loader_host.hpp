@@ -4,11 +4,13 @@
 // pool of host threads straight into ONE caller-owned buffer (the pinned staging buffer of the streaming pipeline), back
 // to back in the order given: the per-file Python loader costs ~15 us a file under the GIL, which is what bounded a rank of
 // the CLI (12 500 x 4096-sample files: 0.19 s of loading against 0.16 s of device work).  Included by catfish_hip.hip.
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <new>
 #include <stdexcept>
@@ -226,4 +228,144 @@ extern "C" int cf_stat_files(const char* dir, const char* names, const int64_t* 
     } catch (const std::exception& e) {
         return fail(CF_ERR_INVALID, std::string("cf_stat_files: ") + e.what());
     }
+}
+
+// The listing of the input directory as an object (catfish/catfish:49-50: `input_files = os.listdir(input_dir)`): every rank of a
+// sharded job needs the same ORDER of all names, the sizes of one block of them and the names of the block it ends up working on --
+// not a Python string per entry of a 100 000-file directory on each of 8 ranks.  Names are read with readdir, ordered bytewise
+// (= sorted() of the decoded names whenever they are valid UTF-8, whose byte order is its code-point order) by an 8-byte key behind the
+// common prefix with strcmp as the tie-break, and kept as one blob.
+struct cf_listing {
+    std::string dir;
+    std::vector<char> blob;              // names, NUL-terminated, in READ order
+    std::vector<uint32_t> at;            // offset of entry i (sorted order) in blob
+};
+
+namespace cf_loader {
+static uint64_t key_of(const char* s, size_t skip) {
+    // the 8 bytes behind the common prefix, big-endian, NUL-padded: integer order = byte order of that stretch
+    uint64_t k = 0;
+    size_t n = strlen(s);
+    for (size_t i = 0; i < 8; ++i) k = (k << 8) | (skip + i < n ? (unsigned char)s[skip + i] : 0u);
+    return k;
+}
+}  // namespace cf_loader
+
+static int listing_open(const char* dir, cf_listing** out, int64_t* n_entries, uint64_t* digest) {
+    if (!dir || !out) return fail(CF_ERR_INVALID, "cf_listing_open: null argument");
+    *out = nullptr;
+    DIR* d = opendir(dir);
+    if (!d) return fail(CF_ERR_INVALID, std::string("cf_listing_open: cannot open directory ") + dir + ": " + strerror(errno));
+    std::unique_ptr<cf_listing> l(new cf_listing);
+    l->dir = dir;
+    std::vector<uint32_t> off;
+    try {
+        for (;;) {
+            errno = 0;
+            const struct dirent* e = readdir(d);
+            if (!e) {
+                if (errno != 0) {
+                    const int err = errno;
+                    closedir(d);
+                    return fail(CF_ERR_INVALID, std::string("cf_listing_open: reading ") + dir + ": " + strerror(err));
+                }
+                break;
+            }
+            const char* nm = e->d_name;
+            if (nm[0] == '.' && (nm[1] == 0 || (nm[1] == '.' && nm[2] == 0))) continue;
+            const size_t len = strlen(nm);
+            if (l->blob.size() + len + 1 > 0xffffffffull) {
+                closedir(d);
+                return fail(CF_ERR_INVALID, "cf_listing_open: more than 4 GiB of names");
+            }
+            off.push_back((uint32_t)l->blob.size());
+            l->blob.insert(l->blob.end(), nm, nm + len + 1);
+        }
+    } catch (...) {
+        closedir(d);
+        throw;
+    }
+    closedir(d);
+    const char* base = l->blob.data();
+    // common prefix of all names ("read_", "channel_12_read_" ...): the key starts behind it
+    size_t skip = off.empty() ? 0 : strlen(base + off[0]);
+    for (size_t i = 1; i < off.size() && skip > 0; ++i) {
+        const char* a = base + off[0];
+        const char* b = base + off[i];
+        size_t k = 0;
+        while (k < skip && a[k] == b[k] && b[k]) ++k;
+        skip = k;
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(off.size());
+    for (size_t i = 0; i < off.size(); ++i) keyed[i] = {cf_loader::key_of(base + off[i], skip), off[i]};
+    std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+        if (x.first != y.first) return x.first < y.first;
+        return strcmp(base + x.second, base + y.second) < 0;        // equal keys: equal up to skip + 8 bytes (or both shorter)
+    });
+    l->at.resize(off.size());
+    // two FNV-1a style 64-bit hashes over the sorted names (NUL included): what the ranks compare
+    uint64_t h0 = 1469598103934665603ull, h1 = 0x9e3779b97f4a7c15ull;
+    for (size_t i = 0; i < keyed.size(); ++i) {
+        l->at[i] = keyed[i].second;
+        for (const char* c = base + keyed[i].second;; ++c) {
+            h0 = (h0 ^ (unsigned char)*c) * 1099511628211ull;
+            h1 = (h1 ^ (unsigned char)*c) * 0x100000001b3ull + 0x632be59bd9b4e019ull;
+            if (!*c) break;
+        }
+    }
+    if (n_entries) *n_entries = (int64_t)l->at.size();
+    if (digest) { digest[0] = h0; digest[1] = h1; }
+    *out = l.release();
+    return CF_OK;
+}
+
+extern "C" int cf_listing_open(const char* dir, cf_listing** out, int64_t* n_entries, uint64_t* digest) {
+    try {
+        return listing_open(dir, out, n_entries, digest);
+    } catch (const std::bad_alloc&) {
+        return fail(CF_ERR_NOMEM, "cf_listing_open: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(CF_ERR_INVALID, std::string("cf_listing_open: ") + e.what());
+    }
+}
+
+extern "C" void cf_listing_close(cf_listing* l) { delete l; }
+
+static bool listing_range_ok(const cf_listing* l, int64_t lo, int64_t hi) { return l && lo >= 0 && lo <= hi && hi <= (int64_t)l->at.size(); }
+
+extern "C" int cf_listing_sizes(const cf_listing* l, int64_t lo, int64_t hi, int64_t* sizes, int32_t n_threads) {
+    if (!listing_range_ok(l, lo, hi)) return fail(CF_ERR_INVALID, "cf_listing_sizes: bad range");
+    if (hi == lo) return CF_OK;
+    if (!sizes) return fail(CF_ERR_INVALID, "cf_listing_sizes: null buffer");
+    try {
+        const int64_t n = hi - lo;
+        std::vector<int64_t> bounds((size_t)n + 1);
+        // stat_files takes names back to back: here they are scattered in the blob, so hand it offsets relative to the blob's start
+        for (int64_t i = 0; i < n; ++i) bounds[(size_t)i] = (int64_t)l->at[(size_t)(lo + i)];
+        bounds[(size_t)n] = 0;
+        return stat_files(l->dir.c_str(), l->blob.data(), bounds.data(), n, sizes, n_threads);
+    } catch (const std::bad_alloc&) {
+        return fail(CF_ERR_NOMEM, "cf_listing_sizes: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(CF_ERR_INVALID, std::string("cf_listing_sizes: ") + e.what());
+    }
+}
+
+extern "C" int cf_listing_names(const cf_listing* l, int64_t lo, int64_t hi, char* out, int64_t capacity, int64_t* bounds, int64_t* needed) {
+    if (!listing_range_ok(l, lo, hi)) return fail(CF_ERR_INVALID, "cf_listing_names: bad range");
+    int64_t total = 0;
+    for (int64_t i = lo; i < hi; ++i) total += (int64_t)strlen(l->blob.data() + l->at[(size_t)i]) + 1;
+    if (needed) *needed = total;
+    if (!out) return CF_OK;                                  // size query
+    if (capacity < total || (!bounds && hi > lo)) return fail(CF_ERR_INVALID, "cf_listing_names: buffer too small");
+    int64_t pos = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        const char* s = l->blob.data() + l->at[(size_t)i];
+        const size_t len = strlen(s) + 1;
+        bounds[i - lo] = pos;
+        memcpy(out + pos, s, len);
+        pos += (int64_t)len;
+    }
+    if (bounds) bounds[hi - lo] = pos;
+    return CF_OK;
 }

@@ -125,20 +125,95 @@ def agree_or_raise(error, stage, group=None, token=None):
             stage, ", ".join(str(r) for r in differing), said[differing[0]][1], said[0][1]))
 
 
-def scan_block(input_dir, rank=0, world_size=1):
-    """This rank's share of listing the input directory (catfish/catfish:49-50 lists it once, in one process): the NAMES of all
-    entries, sorted (one readdir pass, no stat) and the sizes on disk of entries ``[lo, hi)`` = this rank's n/world_size block of
-    them (``stat_sizes``: natively, from a few threads) -- so a directory of 100 000 reads costs every rank one readdir and
-    1/world_size of the stats instead of all of them.  -> (names, lo, int64 sizes of names[lo:hi])."""
-    names = sorted(os.listdir(input_dir))
-    lo, hi = rank * len(names) // world_size, (rank + 1) * len(names) // world_size
-    return names, lo, stat_sizes(input_dir, names[lo:hi])
+class DirListing(object):
+    """The input directory's entries in one agreed order, held by the library (``cf_listing_*``, include/catfish_hip.h): the
+    reference's ``input_files = os.listdir(input_dir)`` (catfish/catfish:49-50) without a Python string per entry.  A rank asks it
+    for the sizes of one block (to cut the list into equal work) and for the names of the block it classifies; the order is bytewise
+    (= ``sorted()`` of the names whenever they are valid UTF-8), ``digest`` is what the ranks compare."""
+
+    def __init__(self, directory):
+        import ctypes as C
+        from . import _native as N
+        self._lib = N.lib()
+        self._handle = C.c_void_p()
+        n, dig = C.c_int64(0), (C.c_uint64 * 2)()
+        N.check(self._lib.cf_listing_open(os.fsencode(directory), C.byref(self._handle), C.byref(n), dig))
+        self.directory = directory
+        self.n = int(n.value)
+        self.digest = "%016x%016x" % (dig[0], dig[1])
+
+    def __len__(self):
+        return self.n
+
+    def sizes(self, lo, hi, n_threads=4):
+        """int64 sizes on disk of entries [lo, hi)."""
+        import ctypes as C
+        from . import _native as N
+        out = np.empty(max(0, hi - lo), dtype=np.int64)
+        N.check(self._lib.cf_listing_sizes(self._handle, int(lo), int(hi), out.ctypes.data_as(C.c_void_p), int(n_threads)))
+        return out
+
+    def names(self, lo=0, hi=None):
+        """The names of entries [lo, hi) as a list of str (this is where Python strings get built: ask for your block only)."""
+        import ctypes as C
+        from . import _native as N
+        hi = self.n if hi is None else hi
+        need = C.c_int64(0)
+        N.check(self._lib.cf_listing_names(self._handle, int(lo), int(hi), None, 0, None, C.byref(need)))
+        if hi <= lo:
+            return []
+        buf = C.create_string_buffer(max(1, int(need.value)))
+        bounds = np.empty(hi - lo + 1, dtype=np.int64)
+        N.check(self._lib.cf_listing_names(self._handle, int(lo), int(hi), buf, int(need.value), bounds.ctypes.data_as(C.c_void_p), None))
+        return os.fsdecode(buf.raw[:int(need.value) - 1]).split("\x00")
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.cf_listing_close(self._handle)
+            self._handle.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ListingPaths(object):
+    """``directory/name`` of every entry of a ``DirListing`` as a sequence that builds strings only for the stretch in use:
+    ``block(lo, hi)`` materialises the paths of [lo, hi) (a rank's files), indexing inside it is a list look-up."""
+
+    def __init__(self, listing):
+        self.listing = listing
+        self._lo, self._paths = 0, []
+
+    def __len__(self):
+        return len(self.listing)
+
+    def block(self, lo, hi):
+        prefix = self.listing.directory.rstrip("/") + "/"
+        self._lo, self._paths = int(lo), [prefix + n for n in self.listing.names(lo, hi)]
+        return self
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if not self._lo <= i < self._lo + len(self._paths):
+            self.block(i, min(len(self), i + 2048))
+        return self._paths[i - self._lo]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 def stat_sizes(directory, names, n_threads=4):
     """Sizes on disk of ``names`` (entries of ``directory``) as int64 -- ``cf_stat_files``: fstatat from the library's host thread
-    pool (a Python loop of os.stat costs 1.5 us per file, 19 ms for a rank's 12 500 reads; this 3-5 ms).  A name that cannot be
-    stat-ed raises ValueError naming it."""
+    pool (a Python loop of os.stat costs 1.5 us per file, 19 ms for a rank's 12 500 reads; this about half).  A name that cannot
+    be stat-ed raises ValueError naming it."""
     import ctypes as C
     from . import _native as N
     sizes = np.empty(len(names), dtype=np.int64)
@@ -153,25 +228,34 @@ def stat_sizes(directory, names, n_threads=4):
     return sizes
 
 
+def scan_block(input_dir, rank=0, world_size=1):
+    """This rank's share of listing the input directory (catfish/catfish:49-50 lists it once, in one process): the library reads
+    and orders ALL names (``DirListing``: one readdir pass, no stat, no Python strings) and stats entries ``[lo, hi)`` = this
+    rank's n/world_size block of them -- a directory of 100 000 reads costs every rank one readdir and 1/world_size of the stats.
+    -> (listing, lo, int64 sizes of entries [lo, hi))."""
+    listing = DirListing(input_dir)
+    lo, hi = rank * len(listing) // world_size, (rank + 1) * len(listing) // world_size
+    return listing, lo, listing.sizes(lo, hi)
+
+
 def agree_on_listing(error, scanned, group=None):
     """Every rank hands in what ``scan_block`` gave it (or the exception that stopped it, or the one of a step before it) and
-    all of them leave with the same ``(names, sizes)`` over the whole directory -- or all raise: the failing rank its own
+    all of them leave with the same ``(listing, sizes)`` over the whole directory -- or all raise: the failing rank its own
     exception, the others a RuntimeError naming it; and when the ranks saw DIFFERENT sets of names (a file still being copied in,
     stale attributes of a network file system on one of them) a RuntimeError naming the ranks that differ from rank 0, because
     blocks cut from differing listings overlap or leave gaps with plausible totals.  One small all-gather (a digest, a count and
     the block's sizes per rank)."""
-    import hashlib
     import torch.distributed as dist
-    names = lo = sizes = digest = None
+    listing = lo = sizes = digest = None
     if error is None:
-        names, lo, sizes = scanned
-        digest = hashlib.sha1("\0".join(names).encode("utf-8", "surrogateescape")).hexdigest()
+        listing, lo, sizes = scanned
+        digest = listing.digest
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         if error is not None:
             raise error
-        return names, [int(s) for s in sizes]
+        return listing, sizes
     said = [None] * dist.get_world_size()
-    mine = (None if error is None else "%s: %s" % (type(error).__name__, error), digest, None if names is None else len(names), lo, sizes)
+    mine = (None if error is None else "%s: %s" % (type(error).__name__, error), digest, None if listing is None else len(listing), lo, sizes)
     dist.all_gather_object(said, mine, group=group)
     if error is not None:
         raise error
@@ -184,9 +268,9 @@ def agree_on_listing(error, scanned, group=None):
         raise RuntimeError("%s: rank(s) %s disagree with rank 0 (%d names, digest %s against %d names, digest %s)" % (
             stage, ", ".join(str(r) for r in differing), said[differing[0]][2], said[differing[0]][1], said[0][2], said[0][1]))
     all_sizes = np.concatenate([t[4] for t in said]) if said else np.zeros(0, np.int64)
-    if [t[3] for t in said] != [r * len(names) // len(said) for r in range(len(said))] or len(all_sizes) != len(names):
+    if [t[3] for t in said] != [r * len(listing) // len(said) for r in range(len(said))] or len(all_sizes) != len(listing):
         raise RuntimeError("%s: the ranks' blocks do not tile the listing" % stage)
-    return names, [int(s) for s in all_sizes]
+    return listing, all_sizes
 
 
 def host_gather_group():
@@ -555,7 +639,7 @@ def _file_costs(paths):
 def _sample_hints(file_sizes):
     """Samples per file estimated from its size on disk (int16 behind numpy's usual 128-byte header); only used to cut
     batches before anything is read -- a batch that turns out too big is re-cut by its true lengths."""
-    return [max(1, (int(c) - 128) // 2) for c in file_sizes]
+    return np.maximum(1, (np.asarray(file_sizes, dtype=np.int64) - 128) // 2)
 
 
 def infer_files_sharded(model, paths, max_samples_per_batch=None, batch_runner=None, rank=None, world_size=None,
@@ -582,16 +666,19 @@ def chunk_files_local(model, paths, chunk_size=1000, max_samples_per_batch=None,
     import time
     from .chunks import ChunkTable
     from .infer import load_dac
-    paths = list(paths)
+    lazy = isinstance(paths, ListingPaths)              # a big directory: path strings only for this rank's block
+    paths = paths if lazy else list(paths)
     if max_samples_per_batch is None:
         max_samples_per_batch = 32768 * WINDOW_SIZE
     env_rank, env_world, _local = dist_env()
     rank = env_rank if rank is None else int(rank)
     world_size = env_world if world_size is None else int(world_size)
-    costs = [max(1, int(c)) for c in file_sizes] if file_sizes is not None else _file_costs(paths)
+    costs = np.maximum(1, np.asarray(file_sizes, dtype=np.int64)) if file_sizes is not None else _file_costs(paths)
     if len(costs) != len(paths):
         raise ValueError("file_sizes must hold one size per path")
     mine = shard_contiguous(costs, world_size)[rank]
+    if lazy and mine:
+        paths.block(mine[0], mine[-1] + 1)
     from .batching import quiet_gc
     with quiet_gc():
         t0 = time.perf_counter()

@@ -218,6 +218,22 @@ int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_f
  * names the first entry that cannot be stat-ed (e.g. removed since the listing) in cf_last_error(). */
 int cf_stat_files(const char* dir, const char* names, const int64_t* name_bounds, int64_t n_files, int64_t* sizes, int32_t n_threads);
 
+/* The listing of the input directory as an object (host code; catfish/catfish:49-50 `input_files = os.listdir(input_dir)`).  Every
+ * rank of a sharded job needs the same ORDER of all names, the sizes of one block of them and the names of the block it ends up
+ * classifying -- not a host-language string per entry of a 100 000-file directory on each of 8 ranks.
+ *   cf_listing_open   reads all entry names of dir (no "." / ".."), orders them bytewise (= sorted() of the decoded names whenever
+ *                     they are valid UTF-8), keeps them; *n_entries their number, digest[2] 128 bits over the ordered names (what
+ *                     the ranks compare to make sure they saw the same directory)
+ *   cf_listing_sizes  st_size of entries [lo, hi) of that order (fstatat from n_threads host threads, as cf_stat_files)
+ *   cf_listing_names  the names of entries [lo, hi), NUL-terminated, back to back into out (capacity bytes) with bounds[hi - lo + 1]
+ *                     their offsets; *needed (may be NULL) the bytes they take; out == NULL: size query only
+ * Not thread-safe per listing; independent listings are. */
+typedef struct cf_listing cf_listing;
+int cf_listing_open(const char* dir, cf_listing** out, int64_t* n_entries, uint64_t* digest);
+int cf_listing_sizes(const cf_listing* l, int64_t lo, int64_t hi, int64_t* sizes, int32_t n_threads);
+int cf_listing_names(const cf_listing* l, int64_t lo, int64_t hi, char* out, int64_t capacity, int64_t* bounds, int64_t* needed);
+void cf_listing_close(cf_listing* l);
+
 /* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
  * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,
  * on device buffers in the kernels' fragment layout [tile][t][mtile][lane][4] (tile = 16 windows; element

@@ -10,6 +10,7 @@ child process with the sanitizer runtime preloaded; not collected by pytest itse
   capacities.  Judge: the per-read Python rules (catfish_amd.cli.chunks_of_read) and json.dumps.
 * cf_stat_files (loader_host.hpp) writes one size per name from several threads: files, empty files, directories, missing entries,
   zero to 700 names.  Judge: os.stat.
+* cf_listing_open / _sizes / _names / _close (loader_host.hpp): random name sets against sorted(), blocks into exactly-sized buffers.
 A sanitizer report aborts the process (non-zero exit); a wrong answer raises.
 """
 import ctypes as C
@@ -35,6 +36,14 @@ lib.cf_chunks_json.restype = C.c_int64
 lib.cf_chunks_json.argtypes = [C.c_char_p, P64, C.c_int64, P64, P64, P64, P8, C.c_char_p, C.c_int64]
 lib.cf_stat_files.restype = C.c_int
 lib.cf_stat_files.argtypes = [C.c_char_p, C.c_char_p, P64, C.c_int64, P64, C.c_int32]
+lib.cf_listing_open.restype = C.c_int
+lib.cf_listing_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), P64, C.POINTER(C.c_uint64)]
+lib.cf_listing_sizes.restype = C.c_int
+lib.cf_listing_sizes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P64, C.c_int32]
+lib.cf_listing_names.restype = C.c_int
+lib.cf_listing_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, P64, P64]
+lib.cf_listing_close.restype = None
+lib.cf_listing_close.argtypes = [C.c_void_p]
 CF_OK, CF_ERR_INVALID = 0, -1
 SETTINGS = dict(deadline=None, database=None, suppress_health_check=list(HealthCheck))
 
@@ -275,6 +284,55 @@ def fuzz_stat(entries, n_threads):
         shutil.rmtree(box, ignore_errors=True)
 
 
+# ------------------------------------------------------------------------------------------------ cf_listing_*
+_NAME = st.builds(lambda p, t: p + t, st.sampled_from(["", "r", "read_", "read_00000000", "ch_"]),
+                  st.text(st.sampled_from(list("0123456789abXY_.~") + ["\u00e9", "\u4e2d"]), min_size=1, max_size=20)).filter(
+                      lambda n: n not in (".", ".."))
+
+
+@settings(max_examples=max(20, int(os.environ.get("FUZZ_EXAMPLES", 250)) // 4), **SETTINGS)
+@given(st.sets(_NAME, min_size=0, max_size=80), st.data())
+def fuzz_listing(names, data):
+    """Names in, order out: against sorted(); every block's names into an exactly-sized buffer (and a too-small one), every block's
+    sizes into an exactly-sized table, ranges off either end refused."""
+    import shutil
+    import tempfile
+    box = tempfile.mkdtemp(dir=SCRATCH)
+    try:
+        for i, n in enumerate(sorted(names)):
+            with open(os.path.join(box, n), "wb") as fh:
+                fh.write(b"\x01" * (i % 9))
+        want = sorted(names)
+        handle, n_entries, digest = C.c_void_p(), C.c_int64(-1), (C.c_uint64 * 2)()
+        assert lib.cf_listing_open(os.fsencode(box), C.byref(handle), C.byref(n_entries), digest) == CF_OK, lib.cf_last_error()
+        try:
+            assert n_entries.value == len(want)
+            lo = data.draw(st.integers(0, len(want)))
+            hi = data.draw(st.integers(lo, len(want)))
+            need = C.c_int64(-1)
+            assert lib.cf_listing_names(handle, lo, hi, None, 0, None, C.byref(need)) == CF_OK
+            enc = [os.fsencode(n) for n in want[lo:hi]]
+            assert need.value == sum(len(e) + 1 for e in enc)
+            buf = C.create_string_buffer(max(need.value, 1))
+            bounds = (C.c_int64 * (hi - lo + 1))()
+            assert lib.cf_listing_names(handle, lo, hi, buf, need.value, bounds, None) == CF_OK
+            assert buf.raw[:need.value] == b"".join(e + b"\x00" for e in enc)
+            assert list(bounds) == list(np.cumsum([0] + [len(e) + 1 for e in enc]))
+            if need.value:
+                small = C.create_string_buffer(max(need.value - 1, 1))
+                assert lib.cf_listing_names(handle, lo, hi, small, need.value - 1, bounds, None) == CF_ERR_INVALID
+            sizes = (C.c_int64 * max(hi - lo, 1))()
+            assert lib.cf_listing_sizes(handle, lo, hi, sizes, data.draw(st.integers(-1, 6))) == CF_OK, lib.cf_last_error()
+            assert list(sizes)[:hi - lo] == [os.stat(os.path.join(box, n)).st_size for n in want[lo:hi]]
+            assert lib.cf_listing_sizes(handle, -1, hi, sizes, 1) == CF_ERR_INVALID
+            assert lib.cf_listing_sizes(handle, lo, len(want) + 1, sizes, 1) == CF_ERR_INVALID
+            assert lib.cf_listing_names(handle, hi + 1, hi, None, 0, None, None) == CF_ERR_INVALID
+        finally:
+            lib.cf_listing_close(handle)
+    finally:
+        shutil.rmtree(box, ignore_errors=True)
+
+
 def bad_arguments():
     """NULL tables, negative sizes, descending bounds: an error code, never a fault."""
     z = arr64([0, 0])
@@ -295,6 +353,11 @@ def bad_arguments():
     assert lib.cf_stat_files(b".", b"x\x00", z, -1, z, 1) == CF_ERR_INVALID
     assert lib.cf_stat_files(os.fsencode(os.path.join(SCRATCH, "no such directory")), b"x\x00", z, 1, arr64([0]), 1) == CF_ERR_INVALID
     assert b"no such directory" in lib.cf_last_error()
+    h = C.c_void_p()
+    assert lib.cf_listing_open(None, C.byref(h), None, None) == CF_ERR_INVALID
+    assert lib.cf_listing_open(os.fsencode(os.path.join(SCRATCH, "no such directory")), C.byref(h), None, None) == CF_ERR_INVALID and not h.value
+    assert lib.cf_listing_sizes(None, 0, 0, None, 1) == CF_ERR_INVALID and lib.cf_listing_names(None, 0, 0, None, 0, None, None) == CF_ERR_INVALID
+    lib.cf_listing_close(None)
 
 
 if __name__ == "__main__":
@@ -302,4 +365,5 @@ if __name__ == "__main__":
     fuzz_loader()
     fuzz_chunks()
     fuzz_stat()
+    fuzz_listing()
     print("fuzz ok")

@@ -356,16 +356,16 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
         def wrong_type(fd, data, offset):
             raise TypeError("a bytes-like object is required, not 'str'")
         chunks._pwrite_all = wrong_type
-    if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet)
-        real_listdir = os.listdir
-        os.listdir = lambda path=".": sorted(real_listdir(path))[:-1] if str(path).endswith("reads") else real_listdir(path)
-    if break_setup == "count-stats":                                       # every name handed to the native stat is counted
-        real_sizes, seen = sharding.stat_sizes, []
+    if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet):
+        real_listing = sharding.DirListing                                 # its listing is of a copy of the directory without it
+        sharding.DirListing = lambda path: real_listing(os.path.join(tmpdir, "reads_stale"))
+    if break_setup == "count-stats":                                       # every entry this rank asks the sizes of is counted
+        real_sizes, seen = sharding.DirListing.sizes, []
 
-        def counting(directory, names, *a, **k):
-            seen.extend(names)
-            return real_sizes(directory, names, *a, **k)
-        sharding.stat_sizes = counting
+        def counting(self, lo, hi, *a, **k):
+            seen.extend(range(lo, hi))
+            return real_sizes(self, lo, hi, *a, **k)
+        sharding.DirListing.sizes = counting
     t0 = time.time()
     try:
         res = cli.run_pipeline(os.path.join(tmpdir, "reads"), os.path.join(tmpdir, out_name), chunk_size=300,
@@ -498,7 +498,10 @@ def test_ranks_that_list_the_input_directory_differently_fail_at_set_up(tmp_path
     listing (a file still being copied in, stale NFS attributes) would silently duplicate or drop reads.  The ranks
     compare a digest of the names in the listing exchange (``sharding.agree_on_listing``; the sizes come from one rank each)."""
     import torch.multiprocessing as mp
+    import shutil
     _write_reads(str(tmp_path / "reads"), 6)
+    shutil.copytree(tmp_path / "reads", tmp_path / "reads_stale")
+    os.unlink(tmp_path / "reads_stale" / sorted(os.listdir(tmp_path / "reads_stale"))[-1])
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 6, "out", "listing"), nprocs=2, join=True)
     r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
     assert float(r0[0]) < 30 and float(r1[0]) < 30

@@ -568,3 +568,81 @@ def test_bf16x3_schedule_compiles_on_the_host_and_is_consistent(tmp_path):
                 m = re.search(r"= ([0-9.]+) per gap", line)
                 if m:
                     assert float(m.group(1)) <= 25.0, line
+
+
+def test_native_directory_listing_orders_like_sorted_and_serves_blocks(tmp_path):
+    """sharding.DirListing (cf_listing_*: readdir + bytewise order by an 8-byte key behind the common prefix, strcmp on ties) against
+    ``sorted(os.listdir())`` -- the order ``cli.run_pipeline`` used to build in Python (catfish/catfish:49-50 lists the directory;
+    sorted, so that N ranks write the same bytes as one).  Names that tie in the key, names shorter than the common prefix + 8,
+    a prefix-of-another name, non-ASCII UTF-8, a sub-directory, hidden files; sizes and names of blocks; the digest."""
+    from catfish_amd import sharding
+    d = tmp_path / "reads"
+    d.mkdir()
+    names = ["read_%05d.npy" % i for i in (3, 1, 2, 10, 100, 99999)] + ["read_", "read_1", "read_12345678", "read_123456789", "read_12345678a",
+             "read_été.npy", "read_zz", "read_~", "read_A", "read_a", "read_0000000000000001.npy", "read_0000000000000002.npy"]
+    for i, n in enumerate(names):
+        (d / n).write_bytes(b"x" * (7 * i))
+    (d / "read_subdir").mkdir()
+    names.append("read_subdir")
+    lst = sharding.DirListing(str(d))
+    want = sorted(os.listdir(d))
+    assert len(lst) == len(names) == len(want) and lst.names() == want
+    assert lst.names(2, 5) == want[2:5] and lst.names(4, 4) == [] and lst.names(len(want) - 1) == want[-1:]
+    sizes = lst.sizes(0, len(lst))
+    assert [int(s) for s in sizes] == [os.stat(d / n).st_size for n in want]
+    assert [int(s) for s in lst.sizes(3, 7, n_threads=3)] == [os.stat(d / n).st_size for n in want[3:7]] and len(lst.sizes(5, 5)) == 0
+    with pytest.raises(ValueError):
+        lst.sizes(3, len(lst) + 1)
+    with pytest.raises(ValueError):
+        lst.names(5, 4)
+    # the same names -> the same digest; one name more, or one renamed -> another
+    again = sharding.DirListing(str(d))
+    assert again.digest == lst.digest and len(lst.digest) == 32
+    (d / "read_00004.npy").write_bytes(b"")
+    assert sharding.DirListing(str(d)).digest != lst.digest
+    os.rename(d / "read_00004.npy", d / "read_00005.npy")
+    more = sharding.DirListing(str(d))
+    assert more.digest != lst.digest and more.names() == sorted(os.listdir(d))
+    # a removed file shows when its size is asked for, by name
+    os.unlink(d / "read_00005.npy")
+    with pytest.raises(ValueError, match="read_00005.npy"):
+        more.sizes(0, len(more))
+    # no common prefix at all, an empty directory, a missing one
+    e = tmp_path / "mixed"
+    e.mkdir()
+    for n in ("b", "a", "ab", "B", "0", "zz.fast5", ".hidden"):
+        (e / n).write_bytes(b"1")
+    assert sharding.DirListing(str(e)).names() == sorted(os.listdir(e))
+    (tmp_path / "empty").mkdir()
+    empty = sharding.DirListing(str(tmp_path / "empty"))
+    assert len(empty) == 0 and empty.names() == [] and len(empty.sizes(0, 0)) == 0
+    with pytest.raises(ValueError, match="cannot open directory"):
+        sharding.DirListing(str(tmp_path / "nowhere"))
+    # path strings for one block only
+    paths = sharding.ListingPaths(lst).block(2, 6)
+    assert len(paths) == len(lst) and paths[2] == str(d / want[2]) and paths[5] == str(d / want[5]) and paths[-1] == str(d / want[-1])
+    assert paths[1:3] == [str(d / want[1]), str(d / want[2])]
+    lst.close(); lst.close()
+
+
+def test_native_directory_listing_property_based(tmp_path):
+    """Random name sets (shared prefixes, digits, mixed case, UTF-8, lengths 1..40): the library's order is sorted()'s."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from catfish_amd import sharding
+    alphabet = st.sampled_from(list("0123456789abcXYZ_-.~") + ["é", "中", "\U0001f600"])
+    name = st.builds(lambda p, t: p + t, st.sampled_from(["", "r", "read_", "read_0000", "channel_100_read_"]),
+                     st.text(alphabet, min_size=1, max_size=24)).filter(lambda n: n not in (".", "..") and len(n.encode()) < 200)
+    counter = [0]
+
+    @settings(max_examples=60, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(st.sets(name, min_size=0, max_size=60))
+    def check(names):
+        counter[0] += 1
+        d = tmp_path / ("d%d" % counter[0])
+        d.mkdir()
+        for n in names:
+            (d / n).write_bytes(b"")
+        lst = sharding.DirListing(str(d))
+        assert lst.names() == sorted(names) == sorted(os.listdir(d))
+        lst.close()
+    check()

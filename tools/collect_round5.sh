@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the round-5 measurements the docs cite, written under gpurun_out/round5/ (copy what is judged into profiles/).
-# usage:  bash tools/collect_round5.sh <commit> [stage ...]     stages: probe tests bench rehearse prof (default: all)
+# usage:  bash tools/collect_round5.sh <commit> [stage ...]     stages: probe tests bench rehearse prof x3abl (default: all but x3abl)
 COMMIT=${1:-unknown}; shift
 STAGES=${@:-probe tests bench rehearse prof}
 ROOT="$GRAFT_REPO_ROOT"
@@ -19,6 +19,9 @@ for S in $STAGES; do
           --master-port $((29500 + N)) bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_${N}ranks_one_gpu.json 2> $OUT/bench_${N}ranks.err \
           || { echo "rehearsal $N FAILED" >> $OUT/commit.txt; tail -20 $OUT/bench_${N}ranks.err; exit 1; }
       done ;;
+    x3abl)   # upper bounds for the bf16x3 layer-0 experiment: timing-only ablations, interleaved rounds on one box
+      bash tools/ab_x3_variants.sh 2 default tools/x3var/libcatfish_x3_abl4.so tools/x3var/libcatfish_x3_abl1.so tools/x3var/libcatfish_x3_abl2.so \
+        > $OUT/x3_layer0_ablation.log 2>&1 ;;
     prof)
       for P in fp32 bf16 bf16x3; do
         rm -rf /tmp/kt_$P
