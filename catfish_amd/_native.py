@@ -101,6 +101,7 @@ SYMBOLS = {
     "cf_load_npy_int16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     "cf_stat_files": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "cf_listing_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
+    "cf_listing_from_names": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "cf_listing_sizes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
     "cf_listing_names": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "cf_listing_close": (None, [C.c_void_p]),

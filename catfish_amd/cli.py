@@ -114,18 +114,17 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         network_path = os.path.abspath(network_path)
         t1 = datetime.datetime.now()
         # 1. output directories + the listing (catfish/catfish:35-38, 49-50).  Part of the job: it grows with the directory, so it is
-        # timed apart from the network load (``listing_s``) and counted by the end-to-end benchmark.  Every rank reads the names,
-        # stats only its n/world block, and the ranks agree on names and sizes (``sharding.agree_on_listing``).
+        # timed apart from the network load (``listing_s``) and counted by the end-to-end benchmark.  Rank 0 reads the names once and
+        # broadcasts them, every rank stats only its n/world block, one all-gather completes the sizes (``sharding.shared_listing``).
         t_list = time.perf_counter()
-        scanned = listing_error = None
-        try:
-            if rank == 0:
+        listing_error = None
+        if rank == 0:
+            try:
                 os.makedirs("{}/HP".format(temp_dir))      # raises if they exist, like the reference (:37-38)
                 os.mkdir("{}/nonHP".format(temp_dir))
-            scanned = sharding.scan_block(input_dir, rank, world)
-        except Exception as exc:                          # noqa: BLE001 -- every rank must learn of it before the data path
-            listing_error = exc
-        listing, file_sizes = sharding.agree_on_listing(listing_error, scanned, group=host_group)
+            except Exception as exc:                      # noqa: BLE001 -- every rank must learn of it before the data path
+                listing_error = exc
+        listing, file_sizes = sharding.shared_listing(input_dir, rank, world, group=host_group, error=listing_error)
         timings["listing_s"] = time.perf_counter() - t_list
         # 2. the network (catfish/catfish:40-47), outside what the benchmark counts (``model_s``, up to the ranks' agreement on it)
         t_model = time.perf_counter()

@@ -142,6 +142,35 @@ class DirListing(object):
         self.n = int(n.value)
         self.digest = "%016x%016x" % (dig[0], dig[1])
 
+    @classmethod
+    def from_names_blob(cls, directory, blob, n_entries):
+        """The listing another rank read: ``blob`` = the ordered names, NUL-terminated, back to back (``names_blob``)."""
+        import ctypes as C
+        from . import _native as N
+        self = cls.__new__(cls)
+        self._lib = N.lib()
+        self._handle = C.c_void_p()
+        dig = (C.c_uint64 * 2)()
+        N.check(self._lib.cf_listing_from_names(os.fsencode(directory), blob, len(blob), int(n_entries), C.byref(self._handle), dig))
+        self.directory, self.n, self.digest = directory, int(n_entries), "%016x%016x" % (dig[0], dig[1])
+        return self
+
+    def names_blob(self, lo=0, hi=None):
+        """The names of entries [lo, hi) as bytes: NUL-terminated, back to back, in order (what travels between ranks)."""
+        return self._names_raw(lo, self.n if hi is None else hi)[0]
+
+    def _names_raw(self, lo, hi):
+        import ctypes as C
+        from . import _native as N
+        need = C.c_int64(0)
+        N.check(self._lib.cf_listing_names(self._handle, int(lo), int(hi), None, 0, None, C.byref(need)))
+        if hi <= lo:
+            return b"", np.zeros(1, dtype=np.int64)
+        buf = C.create_string_buffer(max(1, int(need.value)))
+        bounds = np.empty(hi - lo + 1, dtype=np.int64)
+        N.check(self._lib.cf_listing_names(self._handle, int(lo), int(hi), buf, int(need.value), bounds.ctypes.data_as(C.c_void_p), None))
+        return buf.raw[:int(need.value)], bounds
+
     def __len__(self):
         return self.n
 
@@ -155,17 +184,9 @@ class DirListing(object):
 
     def names(self, lo=0, hi=None):
         """The names of entries [lo, hi) as a list of str (this is where Python strings get built: ask for your block only)."""
-        import ctypes as C
-        from . import _native as N
         hi = self.n if hi is None else hi
-        need = C.c_int64(0)
-        N.check(self._lib.cf_listing_names(self._handle, int(lo), int(hi), None, 0, None, C.byref(need)))
-        if hi <= lo:
-            return []
-        buf = C.create_string_buffer(max(1, int(need.value)))
-        bounds = np.empty(hi - lo + 1, dtype=np.int64)
-        N.check(self._lib.cf_listing_names(self._handle, int(lo), int(hi), buf, int(need.value), bounds.ctypes.data_as(C.c_void_p), None))
-        return os.fsdecode(buf.raw[:int(need.value) - 1]).split("\x00")
+        blob = self._names_raw(lo, hi)[0]
+        return os.fsdecode(blob[:-1]).split("\x00") if hi > lo else []
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -228,47 +249,57 @@ def stat_sizes(directory, names, n_threads=4):
     return sizes
 
 
-def scan_block(input_dir, rank=0, world_size=1):
-    """This rank's share of listing the input directory (catfish/catfish:49-50 lists it once, in one process): the library reads
-    and orders ALL names (``DirListing``: one readdir pass, no stat, no Python strings) and stats entries ``[lo, hi)`` = this
-    rank's n/world_size block of them -- a directory of 100 000 reads costs every rank one readdir and 1/world_size of the stats.
-    -> (listing, lo, int64 sizes of entries [lo, hi))."""
-    listing = DirListing(input_dir)
-    lo, hi = rank * len(listing) // world_size, (rank + 1) * len(listing) // world_size
-    return listing, lo, listing.sizes(lo, hi)
+def shared_listing(input_dir, rank=0, world_size=1, group=None, error=None):
+    """The listing step of the sharded per-file loop (catfish/catfish:49-50 lists the directory once, in one process) ->
+    ``(listing, sizes)``: a ``DirListing`` over ALL entries in one order and their int64 sizes on disk, the same on every rank.
 
+    RANK 0 READS THE DIRECTORY, once, and broadcasts the ordered names (1.6 MB for 100 000 reads); every rank builds its listing
+    from them and stats only entries ``[rank n / N, (rank + 1) n / N)`` (fstatat from the library's threads); one all-gather
+    completes the sizes.  Why one reader: concurrent readdirs of ONE directory serialise on some file systems -- on the MI355X boxes'
+    overlayfs 8 ranks x 100 000 entries took 102 ms EACH against 13 ms for a single reader (tools/exp_listing.py,
+    profiles/r05_listing_concurrency.log) -- so N readers cost N times the one reader everybody would otherwise wait for.
 
-def agree_on_listing(error, scanned, group=None):
-    """Every rank hands in what ``scan_block`` gave it (or the exception that stopped it, or the one of a step before it) and
-    all of them leave with the same ``(listing, sizes)`` over the whole directory -- or all raise: the failing rank its own
-    exception, the others a RuntimeError naming it; and when the ranks saw DIFFERENT sets of names (a file still being copied in,
-    stale attributes of a network file system on one of them) a RuntimeError naming the ranks that differ from rank 0, because
-    blocks cut from differing listings overlap or leave gaps with plausible totals.  One small all-gather (a digest, a count and
-    the block's sizes per rank)."""
+    ``error``: the exception of a step before (rank 0 could not create the output directories): it travels in the listing's place.
+    Failure anywhere -- rank 0 cannot read the directory, a rank cannot stat an entry of its block (gone since the listing, or not
+    visible from that rank: a file still being copied in, a stale network file system) -- raises on EVERY rank: the failing one
+    its own exception, the others a RuntimeError naming rank and cause; nobody walks on with a list the others do not share."""
     import torch.distributed as dist
-    listing = lo = sizes = digest = None
-    if error is None:
-        listing, lo, sizes = scanned
-        digest = listing.digest
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    listing = None
+    if rank == 0 and error is None:
+        try:
+            listing = DirListing(input_dir)
+        except Exception as exc:              # noqa: BLE001 -- told to the other ranks below
+            error = exc
+    if not distributed:
         if error is not None:
             raise error
-        return listing, sizes
+        return listing, listing.sizes(0, len(listing))
+    box = [None]
+    if rank == 0:
+        box[0] = ("error", "%s: %s" % (type(error).__name__, error)) if error is not None else (len(listing), listing.names_blob())
+    dist.broadcast_object_list(box, src=0, group=group)
+    sizes = lo = None
+    if box[0][0] != "error" and error is None:
+        try:
+            if rank != 0:
+                listing = DirListing.from_names_blob(input_dir, box[0][1], box[0][0])
+            lo, hi = rank * len(listing) // world_size, (rank + 1) * len(listing) // world_size
+            sizes = listing.sizes(lo, hi)
+        except Exception as exc:              # noqa: BLE001
+            error = exc
     said = [None] * dist.get_world_size()
-    mine = (None if error is None else "%s: %s" % (type(error).__name__, error), digest, None if listing is None else len(listing), lo, sizes)
-    dist.all_gather_object(said, mine, group=group)
+    dist.all_gather_object(said, (None if error is None else "%s: %s" % (type(error).__name__, error), lo, sizes), group=group)
     if error is not None:
         raise error
     stage = "listing the input directory"
+    if box[0][0] == "error":
+        raise RuntimeError("%s failed on rank 0: %s" % (stage, box[0][1]))
     bad = ["rank %d: %s" % (r, t[0]) for r, t in enumerate(said) if t[0] is not None]
     if bad:
         raise RuntimeError("%s failed on %s" % (stage, "; ".join(bad)))
-    differing = [r for r, t in enumerate(said) if (t[1], t[2]) != (said[0][1], said[0][2])]
-    if differing:
-        raise RuntimeError("%s: rank(s) %s disagree with rank 0 (%d names, digest %s against %d names, digest %s)" % (
-            stage, ", ".join(str(r) for r in differing), said[differing[0]][2], said[differing[0]][1], said[0][2], said[0][1]))
-    all_sizes = np.concatenate([t[4] for t in said]) if said else np.zeros(0, np.int64)
-    if [t[3] for t in said] != [r * len(listing) // len(said) for r in range(len(said))] or len(all_sizes) != len(listing):
+    all_sizes = np.concatenate([t[2] for t in said])
+    if [t[1] for t in said] != [r * len(listing) // len(said) for r in range(len(said))] or len(all_sizes) != len(listing):
         raise RuntimeError("%s: the ranks' blocks do not tile the listing" % stage)
     return listing, all_sizes
 

@@ -42,6 +42,8 @@ lib.cf_listing_sizes.restype = C.c_int
 lib.cf_listing_sizes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P64, C.c_int32]
 lib.cf_listing_names.restype = C.c_int
 lib.cf_listing_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, P64, P64]
+lib.cf_listing_from_names.restype = C.c_int
+lib.cf_listing_from_names.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
 lib.cf_listing_close.restype = None
 lib.cf_listing_close.argtypes = [C.c_void_p]
 CF_OK, CF_ERR_INVALID = 0, -1
@@ -327,6 +329,22 @@ def fuzz_listing(names, data):
             assert lib.cf_listing_sizes(handle, -1, hi, sizes, 1) == CF_ERR_INVALID
             assert lib.cf_listing_sizes(handle, lo, len(want) + 1, sizes, 1) == CF_ERR_INVALID
             assert lib.cf_listing_names(handle, hi + 1, hi, None, 0, None, None) == CF_ERR_INVALID
+            # the ordered names as they travel between ranks -> the same listing; damaged blobs are refused (exactly-sized copies)
+            assert lib.cf_listing_names(handle, 0, len(want), None, 0, None, C.byref(need)) == CF_OK
+            whole = C.create_string_buffer(max(need.value, 1))
+            all_bounds = (C.c_int64 * (len(want) + 1))()
+            assert lib.cf_listing_names(handle, 0, len(want), whole, need.value, all_bounds, None) == CF_OK
+            blob = whole.raw[:need.value]
+            twin, d2 = C.c_void_p(), (C.c_uint64 * 2)()
+            assert lib.cf_listing_from_names(os.fsencode(box), blob, len(blob), len(want), C.byref(twin), d2) == CF_OK, lib.cf_last_error()
+            assert list(d2) == list(digest)
+            lib.cf_listing_close(twin)
+            if want:
+                for damaged, n in ((blob[:-1], len(want)), (blob, len(want) + 1), (blob, len(want) - 1), (blob + blob, 2 * len(want)),
+                                   (b"\x00" + blob, len(want) + 1)):
+                    t2 = C.c_void_p()
+                    assert lib.cf_listing_from_names(os.fsencode(box), bytes(damaged), len(damaged), n, C.byref(t2), None) == CF_ERR_INVALID
+                    assert not t2.value
         finally:
             lib.cf_listing_close(handle)
     finally:

@@ -356,9 +356,10 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
         def wrong_type(fd, data, offset):
             raise TypeError("a bytes-like object is required, not 'str'")
         chunks._pwrite_all = wrong_type
-    if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet):
-        real_listing = sharding.DirListing                                 # its listing is of a copy of the directory without it
-        sharding.DirListing = lambda path: real_listing(os.path.join(tmpdir, "reads_stale"))
+    if break_setup == "listing" and rank == world - 1:                     # this rank does not see the last file (yet): to it the
+        real_from = sharding.DirListing.from_names_blob                    # input directory is a copy without that file
+        sharding.DirListing.from_names_blob = classmethod(
+            lambda cls, directory, blob, n: real_from(os.path.join(tmpdir, "reads_stale"), blob, n))
     if break_setup == "count-stats":                                       # every entry this rank asks the sizes of is counted
         real_sizes, seen = sharding.DirListing.sizes, []
 
@@ -464,8 +465,9 @@ def test_a_rank_whose_write_fails_with_any_exception_fails_the_job_at_once(tmp_p
 @pytest.mark.timeout(120)
 def test_every_rank_stats_only_its_block_of_the_listing(tmp_path):
     """the listing of the input directory (catfish/catfish:49-50) used to be a scandir + stat of EVERY file on
-    EVERY rank (800 000 stats for 100 000 files on 8 ranks) and was left out of the timed region.  Now a rank reads the names
-    and stats its n/world block; the sizes travel in the agreement.  4 ranks, 10 files: 2 + 3 + 2 + 3 stats, same documents as 1."""
+    EVERY rank (800 000 stats for 100 000 files on 8 ranks) and was left out of the timed region.  Now rank 0 reads the names once
+    and broadcasts them, every rank stats its n/world block, and the sizes travel in one all-gather.  4 ranks, 10 files:
+    2 + 3 + 2 + 3 stats, same documents as 1."""
     import torch.multiprocessing as mp
     _write_reads(str(tmp_path / "reads"), 10)
     mp.spawn(_pipeline_worker, args=(4, _free_port(), str(tmp_path), 10, "out4", "count-stats"), nprocs=4, join=True)
@@ -493,21 +495,35 @@ def test_short_writes_are_completed(tmp_path):
 
 
 @pytest.mark.timeout(120)
-def test_ranks_that_list_the_input_directory_differently_fail_at_set_up(tmp_path):
-    """every rank cuts its block out of its own listing of the input directory; a rank that sees another
-    listing (a file still being copied in, stale NFS attributes) would silently duplicate or drop reads.  The ranks
-    compare a digest of the names in the listing exchange (``sharding.agree_on_listing``; the sizes come from one rank each)."""
-    import torch.multiprocessing as mp
+def test_a_rank_that_cannot_see_a_listed_file_fails_the_job_at_set_up(tmp_path):
+    """ranks must not cut their blocks from different views of the input directory (a file still being copied in,
+    stale NFS attributes): they would silently duplicate or drop reads.  Since round 5 rank 0 reads the directory once and
+    broadcasts the ordered names (``sharding.shared_listing``), so there is ONE list; a rank from whose side a listed file is not
+    there finds out when it stats its block, and every rank fails within seconds, naming rank and file."""
     import shutil
+    import torch.multiprocessing as mp
     _write_reads(str(tmp_path / "reads"), 6)
     shutil.copytree(tmp_path / "reads", tmp_path / "reads_stale")
-    os.unlink(tmp_path / "reads_stale" / sorted(os.listdir(tmp_path / "reads_stale"))[-1])
+    gone = sorted(os.listdir(tmp_path / "reads_stale"))[-1]
+    os.unlink(tmp_path / "reads_stale" / gone)
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 6, "out", "listing"), nprocs=2, join=True)
     r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
     assert float(r0[0]) < 30 and float(r1[0]) < 30
-    assert r0[1].startswith("RuntimeError") and r1[1].startswith("RuntimeError")
-    assert "rank(s) 1 disagree with rank 0" in r0[1] and "rank(s) 1 disagree with rank 0" in r1[1]
+    assert r1[1].startswith("ValueError") and gone in r1[1]
+    assert r0[1].startswith("RuntimeError") and "listing the input directory failed on rank 1" in r0[1] and gone in r0[1]
     assert not (tmp_path / "out" / "TEMP" / "hp_positions.json").exists()
+
+
+@pytest.mark.timeout(120)
+def test_an_unreadable_input_directory_fails_every_rank_with_rank_0s_error(tmp_path):
+    """Rank 0 is the only reader of the directory: when it cannot (here: the path is a file), the broadcast carries its error."""
+    import torch.multiprocessing as mp
+    (tmp_path / "reads").write_text("not a directory")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 0, "out", None), nprocs=2, join=True)
+    r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
+    assert float(r0[0]) < 30 and float(r1[0]) < 30
+    assert r0[1].startswith("ValueError") and "cannot open directory" in r0[1]
+    assert r1[1].startswith("RuntimeError") and "listing the input directory failed on rank 0: ValueError" in r1[1]
 
 
 def test_contiguous_shards_tile_in_order_and_balance():

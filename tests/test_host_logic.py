@@ -622,6 +622,17 @@ def test_native_directory_listing_orders_like_sorted_and_serves_blocks(tmp_path)
     paths = sharding.ListingPaths(lst).block(2, 6)
     assert len(paths) == len(lst) and paths[2] == str(d / want[2]) and paths[5] == str(d / want[5]) and paths[-1] == str(d / want[-1])
     assert paths[1:3] == [str(d / want[1]), str(d / want[2])]
+    # what travels between ranks: the ordered names as one blob; a listing rebuilt from it is the same listing
+    blob = lst.names_blob()
+    twin = sharding.DirListing.from_names_blob(str(d), blob, len(lst))
+    assert twin.digest == lst.digest and twin.names() == want and [int(x) for x in twin.sizes(0, len(twin))] == [int(x) for x in sizes]
+    assert lst.names_blob(2, 4) == b"".join(os.fsencode(n) + b"\x00" for n in want[2:4]) and lst.names_blob(3, 3) == b""
+    for broken in (blob[:-1], blob + b"zzz", b"b\x00a\x00", b"a\x00a\x00", b"\x00"):
+        with pytest.raises(ValueError):
+            sharding.DirListing.from_names_blob(str(d), broken, broken.count(b"\x00"))
+    with pytest.raises(ValueError):
+        sharding.DirListing.from_names_blob(str(d), blob, len(lst) + 1)
+    assert len(sharding.DirListing.from_names_blob(str(d), b"", 0)) == 0
     lst.close(); lst.close()
 
 
