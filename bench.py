@@ -183,6 +183,49 @@ def nearer_roof(roof, precision, samples, seconds):
     return roof
 
 
+def describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, visible_devices):
+    """Who ran what where, into the line (pure bookkeeping, tested on the CPU): ``ranks`` (every rank's record), ``collective``,
+    ``distinct_devices``, ``cpu_sets_disjoint``, and -- when ranks SHARED a card (``CATFISH_BENCH_DEVICE``, or fewer GPUs than
+    ranks) -- the rehearsal marking: ``rehearsal: true``, ``value: null`` (the number moves to ``rehearsal_value``), ``n_gpus`` = the
+    cards actually driven, ``n_ranks`` = N, the same on the two end-to-end legs, ``whole_node_end_to_end: null``.  Nothing in a
+    rehearsal line is an N-GPU number, and nothing in it can be read as one."""
+    from catfish_amd import placement
+    cards = sorted({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks})
+    distinct = len(cards)
+    result["ranks"] = ranks
+    result["collective"] = {"backend": backend, "nccl_init_error": nccl_error, "ranks_seen": ranks_seen,
+                            "ranks_seen_is_world": bool(ranks_seen == world),
+                            "what": "timing barrier + MAX over ranks only (no collective on the data path); ranks_seen = all_reduce(sum) of 1 "
+                                    "per rank over that backend" if world > 1 else "single process: no process group"}
+    result["distinct_devices"] = distinct
+    result["visible_devices_rank0"] = visible_devices
+    cpu_sets = [set(placement.parse_cpulist(r["cpus"])) for r in ranks]
+    result["cpu_sets_disjoint"] = bool(all(not (cpu_sets[i] & cpu_sets[j]) for i in range(len(ranks)) for j in range(i + 1, len(ranks))))
+    result["config"]["parallelism"] = ("reads sharded over %d GPU(s), one rank each, no collective" % world if distinct == world else
+                                       "%d ranks on %d device(s): REHEARSAL of the launch path, not a %d-GPU measurement" % (world, distinct, world))
+    if distinct < world:
+        result["rehearsal"] = True
+        result["rehearsal_value"] = result.pop("unverified_value", None) or result["value"]
+        result["value"] = None
+        result["n_ranks"] = world
+        result["n_gpus"] = distinct
+        for leg in ("sharded_gather", "cli_end_to_end"):
+            if isinstance(result.get(leg), dict) and "n_gpus" in result[leg]:
+                result[leg]["n_ranks"], result[leg]["n_gpus"], result[leg]["rehearsal"] = world, distinct, True
+    else:
+        result["rehearsal"] = False
+    # the two host-inclusive rates at the top level, next to ``value`` (which stays the device-resident configs[1] rate the
+    # roofline is computed on): what a caller holding host buffers gets from one GPU, and what the whole job delivers from files
+    h2h = result.get("host_to_host_pipeline")
+    result["host_to_host_value"] = h2h.get("value") if isinstance(h2h, dict) else None
+    cli_leg = result.get("cli_end_to_end")
+    result["whole_node_end_to_end"] = cli_leg.get("value") if isinstance(cli_leg, dict) else None
+    if result["rehearsal"]:
+        result["rehearsal_whole_node_end_to_end"] = result["whole_node_end_to_end"]
+        result["whole_node_end_to_end"] = None
+    return result
+
+
 def timed_steps(eng, batches, outs, n, torch):
     t0 = time.perf_counter()
     for i in range(n):
@@ -785,39 +828,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        cards = sorted({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks})
-        distinct = len(cards)
-        result["ranks"] = ranks
-        result["collective"] = {"backend": backend, "nccl_init_error": nccl_error, "ranks_seen": ranks_seen,
-                                "what": "timing barrier + MAX over ranks only (no collective on the data path); ranks_seen = all_reduce(sum) of 1 "
-                                        "per rank over that backend" if world > 1 else "single process: no process group"}
-        result["distinct_devices"] = distinct
-        result["visible_devices_rank0"] = torch.cuda.device_count()
-        cpu_sets = [set(placement.parse_cpulist(r["cpus"])) for r in ranks]
-        result["cpu_sets_disjoint"] = bool(all(not (cpu_sets[i] & cpu_sets[j]) for i in range(world) for j in range(i + 1, world)))
-        result["config"]["parallelism"] = ("reads sharded over %d GPU(s), one rank each, no collective" % world if distinct == world else
-                                           "%d ranks on %d device(s): REHEARSAL of the launch path, not a %d-GPU measurement" % (world, distinct, world))
-        if distinct < world:
-            # ranks shared a card (CATFISH_BENCH_DEVICE, or fewer GPUs than ranks): nothing here is an N-GPU number
-            result["rehearsal"] = True
-            result["rehearsal_value"] = result.pop("unverified_value", None) or result["value"]
-            result["value"] = None
-            result["n_ranks"] = world
-            result["n_gpus"] = distinct
-            for leg in ("sharded_gather", "cli_end_to_end"):
-                if isinstance(result.get(leg), dict) and "n_gpus" in result[leg]:
-                    result[leg]["n_ranks"], result[leg]["n_gpus"], result[leg]["rehearsal"] = world, distinct, True
-        else:
-            result["rehearsal"] = False
-        # the two host-inclusive rates at the top level, next to ``value`` (which stays the device-resident configs[1] rate the
-        # roofline is computed on): what a caller holding host buffers gets from one GPU, and what the whole job delivers from files
-        h2h = result.get("host_to_host_pipeline")
-        result["host_to_host_value"] = h2h.get("value") if isinstance(h2h, dict) else None
-        cli_leg = result.get("cli_end_to_end")
-        result["whole_node_end_to_end"] = cli_leg.get("value") if isinstance(cli_leg, dict) else None
-        if result["rehearsal"]:
-            result["rehearsal_whole_node_end_to_end"] = result["whole_node_end_to_end"]
-            result["whole_node_end_to_end"] = None
+        describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, torch.cuda.device_count())
         print(json.dumps(result))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY GATE FAILED (max |dp| %.3g, label match %.5f): no value reported\n" % (max_dp, match))

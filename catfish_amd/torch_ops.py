@@ -1,0 +1,153 @@
+"""``torch.ops.catfish.resnetrnn_forward(x, packed_weights) -> Tensor`` -- the one call this library replaces,
+
+    confidences = self.sess.run(self.predictions, feed_dict={self.x: input_x, self.p_dropout: 1.0})
+                                                                  (reference catfish/models/rnn_class.py:214-216)
+
+registered as a PyTorch operator (SURVEY.md section 8b sketches exactly this name), for callers that live in torch: device tensor
+in, device tensor out, asynchronous on PyTorch's current HIP stream, no host round trip.  It is a thin door to the same C ABI as
+everything else (``cf_infer`` through ``HipEngine.infer_device``): there is NO CPU implementation -- a CPU tensor is refused, and
+without the built library the call raises ``NativeLibraryMissing``.
+
+``packed_weights``: ONE flat float32 CPU tensor made by ``pack_weights(weights, ...)`` -- a 8-value header
+``[magic, n_layers, layer_size, n_layers_res, layer_size_res, n_tensors, 0, 0]`` followed by the checkpoint's inference tensors in
+the fixed order of ``tensor_names`` (TF variable names, TF layouts), i.e. what ``checkpoint.read_inference_weights`` returns, flattened.
+The engine built from it (BN folded, matrices re-tiled into MFMA fragment order, uploaded) is cached per (tensor storage, version,
+device): the second call with the same tensor only launches.
+
+    import torch, catfish_amd.torch_ops as ops
+    packed = ops.pack_weights(weights)                       # once
+    probs = torch.ops.catfish.resnetrnn_forward(x, packed)   # x: float32 [N, 35] or [N, 35, 1] on an MI355X -> float32 [N * 35]
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as N
+
+MAGIC = 35064.0          # "catfish 35-sample windows, 64 units": any float32-exact constant would do
+HEADER = 8
+OP_NAME = "catfish::resnetrnn_forward"
+
+
+def tensor_names(n_layers=3, n_layers_res=2):
+    """The inference tensors of a checkpoint in the operator's packing order (TF variable names)."""
+    names = []
+    for j in range(4 * n_layers_res):
+        names += [N.conv_name(j) + "/kernel", N.conv_name(j) + "/bias"]
+        names += [N.bn_name(j) + "/" + v for v in ("gamma", "beta", "moving_mean", "moving_variance")]
+    for layer in range(n_layers):
+        for d in ("fw", "bw"):
+            p = N.gru_prefix(layer, d)
+            names += [p + "/gates/kernel", p + "/gates/bias", p + "/candidate/kernel", p + "/candidate/bias"]
+    names += ["final_fully_connected/kernel", "final_fully_connected/bias"]
+    return names
+
+
+def _shapes(n_layers, layer_size, n_layers_res, layer_size_res):
+    """name -> shape for a geometry (resnet_class.py:44-82, rnn_class.py:142-183): needed to cut the flat tensor apart again."""
+    shapes = {}
+    for j in range(4 * n_layers_res):
+        block, which = divmod(j, 4)
+        cin = 1 if (block == 0 and which in (0, 1)) else layer_size_res          # shortcut and first conv of block 0 see the signal
+        ksize = 3 if which == 2 else 1
+        shapes[N.conv_name(j) + "/kernel"] = (ksize, cin, layer_size_res)
+        shapes[N.conv_name(j) + "/bias"] = (layer_size_res,)
+        for v in ("gamma", "beta", "moving_mean", "moving_variance"):
+            shapes[N.bn_name(j) + "/" + v] = (layer_size_res,)
+    feat = layer_size_res if n_layers_res else 1
+    for layer in range(n_layers):
+        cin = feat if layer == 0 else 2 * layer_size
+        for d in ("fw", "bw"):
+            p = N.gru_prefix(layer, d)
+            shapes[p + "/gates/kernel"] = (cin + layer_size, 2 * layer_size)
+            shapes[p + "/gates/bias"] = (2 * layer_size,)
+            shapes[p + "/candidate/kernel"] = (cin + layer_size, layer_size)
+            shapes[p + "/candidate/bias"] = (layer_size,)
+    shapes["final_fully_connected/kernel"] = (2 * layer_size, 1)
+    shapes["final_fully_connected/bias"] = (1,)
+    return shapes
+
+
+def pack_weights(weights, n_layers=3, layer_size=64, n_layers_res=2, layer_size_res=32):
+    """dict {TF variable name: array} -> the operator's flat float32 CPU tensor (header + tensors in ``tensor_names`` order).
+    A missing tensor or one of another shape raises ValueError naming it."""
+    import torch
+    names = tensor_names(n_layers, n_layers_res)
+    shapes = _shapes(n_layers, layer_size, n_layers_res, layer_size_res)
+    parts = [np.array([MAGIC, n_layers, layer_size, n_layers_res, layer_size_res, len(names), 0, 0], dtype=np.float32)]
+    for name in names:
+        if name not in weights:
+            raise ValueError("checkpoint is missing tensor %r" % name)
+        arr = np.asarray(weights[name], dtype=np.float32)
+        if tuple(arr.shape) != shapes[name]:
+            raise ValueError("tensor %r has shape %s, the geometry needs %s" % (name, tuple(arr.shape), shapes[name]))
+        parts.append(arr.reshape(-1))
+    return torch.from_numpy(np.concatenate(parts))
+
+
+def unpack_weights(packed):
+    """The inverse: flat tensor -> (dict of arrays, dict(n_layers, layer_size, n_layers_res, layer_size_res)); ValueError when the
+    tensor is not one ``pack_weights`` made (dtype, device, magic, length)."""
+    import torch
+    if not isinstance(packed, torch.Tensor) or packed.dtype != torch.float32 or packed.dim() != 1 or packed.is_cuda:
+        raise ValueError("packed_weights must be the flat float32 CPU tensor pack_weights() returns")
+    flat = packed.detach().contiguous().numpy()
+    if flat.shape[0] < HEADER or flat[0] != MAGIC:
+        raise ValueError("packed_weights does not start with the catfish header")
+    geom = dict(n_layers=int(flat[1]), layer_size=int(flat[2]), n_layers_res=int(flat[3]), layer_size_res=int(flat[4]))
+    names = tensor_names(geom["n_layers"], geom["n_layers_res"])
+    shapes = _shapes(**geom)
+    if int(flat[5]) != len(names) or flat.shape[0] != HEADER + sum(int(np.prod(shapes[n])) for n in names):
+        raise ValueError("packed_weights has %d values, its header describes %d tensors / %d values" % (
+            flat.shape[0], len(names), HEADER + sum(int(np.prod(shapes[n])) for n in names)))
+    out, pos = {}, HEADER
+    for name in names:
+        n = int(np.prod(shapes[name]))
+        out[name] = flat[pos:pos + n].reshape(shapes[name])
+        pos += n
+    return out, geom
+
+
+_ENGINES = {}            # (storage pointer, tensor version, numel, device index) -> HipEngine
+MAX_CACHED = 8
+
+
+def _engine_for(packed, device_index):
+    from .engine import HipEngine
+    key = (packed.untyped_storage().data_ptr(), packed._version, packed.numel(), int(device_index))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        weights, geom = unpack_weights(packed)
+        eng = HipEngine(weights, device=int(device_index), **geom)
+        if len(_ENGINES) >= MAX_CACHED:                       # oldest out: an engine holds device workspace
+            _ENGINES.pop(next(iter(_ENGINES))).close()
+        _ENGINES[key] = eng
+    return eng
+
+
+def clear_engine_cache():
+    """Free the engines (device weights + workspace) the operator built so far."""
+    while _ENGINES:
+        _ENGINES.popitem()[1].close()
+
+
+def _register():
+    import torch
+
+    @torch.library.custom_op(OP_NAME, mutates_args=(), schema="(Tensor x, Tensor packed_weights) -> Tensor")
+    def resnetrnn_forward(x, packed_weights):
+        # the C ABI behind it has no CPU path: a CPU tensor is an error, not a slow answer
+        if not x.is_cuda:
+            raise ValueError("catfish::resnetrnn_forward runs on an MI355X only: x must be a float32 CUDA tensor [N, 35(, 1)]")
+        eng = _engine_for(packed_weights, x.device.index)
+        return eng.infer_device(x)                            # asynchronous on torch.cuda.current_stream(x.device)
+
+    @resnetrnn_forward.register_fake
+    def _(x, packed_weights):
+        n = x.shape[0]
+        return x.new_empty((n * N.CF_WINDOW,), dtype=torch.float32)
+
+    return resnetrnn_forward
+
+
+resnetrnn_forward = _register()

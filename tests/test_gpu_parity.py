@@ -563,3 +563,46 @@ def test_bf16x3_pipelined_kernel_at_other_depths(n_layers, n):
         assert np.array_equal(np.concatenate([eng.infer_host(x[:n // 3]), eng.infer_host(x[n // 3:])]), got)
     finally:
         eng.close()
+
+
+def test_torch_operator_resnetrnn_forward(ckpt_weights, golden_read):
+    """the replaced call (rnn_class.py:214-216) as ``torch.ops.catfish.resnetrnn_forward(x, packed_weights)`` -- device
+    tensor in, device tensor out on PyTorch's current stream, the same C ABI underneath: bit-identical to ``HipEngine.infer_device``,
+    within 1e-4 of the fp64 oracle; the engine is built once per packed tensor; another geometry packs and runs too; a side stream
+    is honoured."""
+    import torch
+    import catfish_amd.torch_ops as ops
+    from catfish_amd.engine import HipEngine
+    ops.clear_engine_cache()
+    packed = ops.pack_weights(ckpt_weights)
+    x = torch.from_numpy(np.ascontiguousarray(golden_read["x"], dtype=np.float32)).cuda()              # [118, 35, 1]
+    got = torch.ops.catfish.resnetrnn_forward(x, packed)
+    assert got.is_cuda and got.dtype == torch.float32 and got.shape == (x.shape[0] * 35,)
+    want = oracle.forward(golden_read["x"], ckpt_weights, np.float64)
+    assert np.abs(got.cpu().numpy() - want).max() < TOL
+    eng = HipEngine(ckpt_weights, device=0)
+    try:
+        assert torch.equal(got, eng.infer_device(x))
+    finally:
+        eng.close()
+    assert len(ops._ENGINES) == 1
+    again = torch.ops.catfish.resnetrnn_forward(x.reshape(-1, 35), packed)                              # [N, 35] is accepted as well
+    assert torch.equal(again, got) and len(ops._ENGINES) == 1                                           # same tensor: same engine
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        on_side = torch.ops.catfish.resnetrnn_forward(x, packed)
+    side.synchronize()
+    assert torch.equal(on_side, got)
+    # another geometry of the operator surface (one biGRU layer, one residual block, random weights)
+    w = oracle.random_weights(seed=3, n_layers=1, n_layers_res=1)
+    small = ops.pack_weights(w, n_layers=1, n_layers_res=1)
+    xs = torch.randn(50, 35, device="cuda")
+    ys = torch.ops.catfish.resnetrnn_forward(xs, small)
+    assert np.abs(ys.cpu().numpy() - oracle.forward(xs.cpu().numpy(), w, np.float64, n_layers=1, n_layers_res=1)).max() < TOL
+    assert len(ops._ENGINES) == 2
+    with pytest.raises(ValueError):
+        torch.ops.catfish.resnetrnn_forward(x.cpu(), packed)                                            # no CPU path
+    with pytest.raises(ValueError):
+        torch.ops.catfish.resnetrnn_forward(x.reshape(-1, 59), packed)                                  # windows are 35 samples
+    ops.clear_engine_cache()
+    assert not ops._ENGINES

@@ -657,3 +657,76 @@ def test_native_directory_listing_property_based(tmp_path):
         assert lst.names() == sorted(names) == sorted(os.listdir(d))
         lst.close()
     check()
+
+
+def test_bench_line_describes_its_ranks_and_refuses_to_call_a_rehearsal_a_measurement():
+    """bench.describe_ranks on made-up rank records -- four ranks on four cards: a measurement (value kept,
+    n_gpus 4); four ranks on ONE card: ``rehearsal: true``, ``value: null``, ``n_gpus: 1``, ``n_ranks: 4``, the legs marked, the
+    whole-node rate withheld; overlapping CPU sets are seen; one process is one device and no rehearsal."""
+    import bench
+
+    def rank(r, uuid, cpus, host="node0"):
+        return {"rank": r, "local_rank": r, "device_index": r, "pci_bus_id": "0000:%02x:00.0" % (10 + r), "uuid": uuid, "host": host,
+                "cpus": cpus, "dt_s": 0.1, "ms_per_step": 3.2}
+
+    def line(world):
+        return {"value": 1.0e9, "n_gpus": world, "config": {"workload": "w"}, "host_to_host_pipeline": {"value": 3.0e8},
+                "sharded_gather": {"value": 2.9e8, "n_gpus": world}, "cli_end_to_end": {"value": 2.8e8, "n_gpus": world}}
+
+    real = bench.describe_ranks(line(4), [rank(r, "uuid%d" % r, "%d-%d" % (16 * r, 16 * r + 15)) for r in range(4)], 4, "nccl", None, 4, 8)
+    assert real["rehearsal"] is False and real["value"] == 1.0e9 and real["n_gpus"] == 4 and real["distinct_devices"] == 4
+    assert real["cpu_sets_disjoint"] is True and real["whole_node_end_to_end"] == 2.8e8 and real["host_to_host_value"] == 3.0e8
+    assert real["collective"] == dict(real["collective"], backend="nccl", nccl_init_error=None, ranks_seen=4, ranks_seen_is_world=True)
+    assert "4 GPU(s), one rank each" in real["config"]["parallelism"] and len(real["ranks"]) == 4
+
+    same = bench.describe_ranks(line(4), [rank(r, "uuid0", "%d-%d" % (16 * r, 16 * r + 15)) for r in range(4)], 4, "gloo",
+                                "DistBackendError: Duplicate GPU detected", 4, 1)
+    assert same["rehearsal"] is True and same["value"] is None and same["rehearsal_value"] == 1.0e9
+    assert same["n_gpus"] == 1 and same["n_ranks"] == 4 and same["distinct_devices"] == 1
+    assert same["whole_node_end_to_end"] is None and same["rehearsal_whole_node_end_to_end"] == 2.8e8
+    assert "4 ranks on 1 device(s): REHEARSAL" in same["config"]["parallelism"]
+    assert same["cli_end_to_end"]["rehearsal"] is True and same["cli_end_to_end"]["n_gpus"] == 1 and same["sharded_gather"]["n_ranks"] == 4
+    assert same["collective"]["backend"] == "gloo" and "Duplicate GPU" in same["collective"]["nccl_init_error"]
+
+    # two ranks on two hosts with equal uuids are two cards; overlapping CPU sets are reported; a failed parity gate keeps value null
+    two = line(2)
+    two.update(value=None, unverified_value=7.0)
+    out = bench.describe_ranks(two, [rank(0, "u", "0-7", "a"), rank(1, "u", "4-11", "b")], 2, "gloo", None, 1, 1)
+    assert out["rehearsal"] is False and out["distinct_devices"] == 2 and out["cpu_sets_disjoint"] is False and out["value"] is None
+    assert out["collective"]["ranks_seen_is_world"] is False
+    one = bench.describe_ranks(line(1), [rank(0, "u", "0-63,128-191")], 1, None, None, 1, 1)
+    assert one["rehearsal"] is False and one["n_gpus"] == 1 and one["value"] == 1.0e9 and "single process" in one["collective"]["what"]
+
+
+def test_torch_operator_is_registered_and_has_no_cpu_path():
+    """``torch.ops.catfish.resnetrnn_forward(x, packed_weights) -> Tensor`` exists with that schema; the packed tensor is
+    the checkpoint's 74 inference tensors behind an 8-value header and unpacks to the same arrays; shape inference works without a
+    device (meta / fake tensors); a CPU input is an error, never a slow answer."""
+    import torch
+    import catfish_amd.torch_ops as ops
+    with np.load(os.path.join(ROOT, "tests", "golden", "ckpnt-30000-inference.npz")) as z:
+        w = {k: z[k] for k in z.files}
+    assert str(torch.ops.catfish.resnetrnn_forward.default._schema) == "catfish::resnetrnn_forward(Tensor x, Tensor packed_weights) -> Tensor"
+    packed = ops.pack_weights(w)
+    assert packed.dtype == torch.float32 and packed.shape == (8 + 197185,) and not packed.is_cuda          # 197 185 parameters (SURVEY 8a-11)
+    assert sorted(ops.tensor_names()) == sorted(w) and len(ops.tensor_names()) == 74
+    back, geom = ops.unpack_weights(packed)
+    assert geom == dict(n_layers=3, layer_size=64, n_layers_res=2, layer_size_res=32)
+    assert all(np.array_equal(back[k], w[k]) and back[k].shape == w[k].shape for k in w)
+    assert torch.ops.catfish.resnetrnn_forward(torch.empty(10, 35, device="meta"), packed).shape == (350,)
+    with pytest.raises(ValueError, match="MI355X only"):
+        torch.ops.catfish.resnetrnn_forward(torch.zeros(4, 35), packed)
+    bad = dict(w)
+    del bad["conv1d_3/bias"]
+    with pytest.raises(ValueError, match="conv1d_3/bias"):
+        ops.pack_weights(bad)
+    with pytest.raises(ValueError, match="shape"):
+        ops.pack_weights(w, layer_size=32)
+    for broken in (packed[:-1], packed.double(), torch.zeros(10), packed.reshape(1, -1)):
+        with pytest.raises(ValueError):
+            ops.unpack_weights(broken)
+    from oracle import catfish_oracle as oracle
+    rnn = oracle.random_weights(seed=1, n_layers=2, n_layers_res=0)                                          # the plain RNN type: no conv stack
+    p2 = ops.pack_weights(rnn, n_layers=2, n_layers_res=0)
+    b2, g2 = ops.unpack_weights(p2)
+    assert g2["n_layers_res"] == 0 and sorted(b2) == sorted(ops.tensor_names(2, 0)) and b2[ops.tensor_names(2, 0)[0]].shape == (1 + 64, 128)
