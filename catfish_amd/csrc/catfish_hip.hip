@@ -921,6 +921,8 @@ __global__ __launch_bounds__(256) void normalize_kernel(const int16_t* __restric
         out[i] = i < n ? (float)(((double)v[i] - shift) / scale) : 0.f;
 }
 
+#include "ingest_post.hpp"      // round 5: normalize_regs_kernel, postprocess_bits_kernel (same results, see there)
+
 // ==========================================================================================
 // Host side
 // ==========================================================================================
@@ -1787,8 +1789,15 @@ extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* re
     size_t pi = 0;
     int rc = prof_begin(m, SLOT_POST, s, &pi);
     if (rc != CF_OK) return rc;
-    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, probs, read_offsets,
-                       read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
+    const bool v1 = cf_knob("CATFISH_INGEST_V1") && atoi(cf_knob("CATFISH_INGEST_V1")) != 0;
+    if (v1 || min_run > 64) {                 // the bit-mask kernel's window covers runs of up to 64 samples (the reference uses 15)
+        hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, probs, read_offsets,
+                           read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
+    } else {
+        const int64_t n_words = (total_samples + 63) / 64, n_chunks = (n_words + CF_POST_WORDS - 1) / CF_POST_WORDS;
+        hipLaunchKernelGGL(postprocess_bits_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, probs, read_offsets,
+                           read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
+    }
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
 }
@@ -1822,7 +1831,12 @@ extern "C" int cf_normalize(cf_model* m, const int16_t* dac, const int64_t* dac_
     size_t pi = 0;
     int rc = prof_begin(m, SLOT_NORM, s, &pi);
     if (rc != CF_OK) return rc;
-    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)n_reads), dim3(256), 0, s, dac, dac_offsets, win_offsets, x_out);
+    if (cf_knob("CATFISH_INGEST_V1") && atoi(cf_knob("CATFISH_INGEST_V1")) != 0)      // A/B and bit-identity tests: round 1's kernel
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)n_reads), dim3(256), 0, s, dac, dac_offsets, win_offsets, x_out);
+    else {                                                                              // reads <= 4096 samples, then the longer ones
+        hipLaunchKernelGGL(normalize_regs_kernel<CF_NORM_REGS_SMALL>, dim3((unsigned)n_reads), dim3(256), 0, s, dac, dac_offsets, win_offsets, x_out);
+        hipLaunchKernelGGL(normalize_regs_kernel<CF_NORM_REGS_LARGE>, dim3((unsigned)n_reads), dim3(256), 0, s, dac, dac_offsets, win_offsets, x_out);
+    }
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
 }

@@ -1035,3 +1035,99 @@ def test_configs1_at_full_size_is_invariant_to_the_launch_size(ckpt_weights):
         eng.check_error()
     finally:
         eng.close()
+
+
+def _normalise_on_device(engine, reads):
+    import torch
+    from catfish_amd import infer
+    dev = torch.device("cuda", 0)
+    lens = [len(r) for r in reads]
+    dac_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    n_win = [(n + infer.padding_size_for(n)) // 35 for n in lens]
+    win_off = np.concatenate(([0], np.cumsum(n_win))).astype(np.int64)
+    x = engine.normalize_device(torch.from_numpy(np.concatenate(reads)).to(dev), torch.from_numpy(dac_off).to(dev),
+                                torch.from_numpy(win_off).to(dev)).cpu().numpy()
+    return x, win_off
+
+
+def test_register_ingest_kernel_is_bit_exact_at_every_length_class(model, monkeypatch):
+    """normalize_regs_kernel<16> (reads <= 4096 samples, in registers), <64> (<= 16 384) and the radix path behind it (longer), against
+    numpy's float64 normalisation cast to float32 (catfish/infer.py:96-105) AND against round 1's kernel (CATFISH_INGEST_V1 behind
+    the debug switch): every length class and their edges, odd and even lengths (the upper middle element comes from a different
+    code path), squiggles (a few hundred distinct codes: heavy ties), the full int16 range, constant reads (MAD = 0: inf / nan like
+    numpy), two-valued reads, reads next to each other whose classes differ."""
+    from catfish_amd import infer
+    rng = np.random.default_rng(11)
+    lens = [1, 2, 3, 4, 255, 256, 257, 511, 512, 1000, 4095, 4096, 4097, 5000, 8191, 8192, 16383, 16384, 16385, 20001, 40000]
+    reads = [np.clip(np.rint(rng.normal(500, 60, size=n)), 0, 2047).astype(np.int16) for n in lens]
+    reads += [rng.integers(-32768, 32768, size=n).astype(np.int16) for n in (2, 77, 4096, 9999, 16384, 30000)]
+    reads += [np.full(n, 417, dtype=np.int16) for n in (1, 2, 4096, 5000)]                       # constant: scale 0
+    reads += [np.array([-32768, 32767] * 50, dtype=np.int16), np.array([-32768] * 7 + [32767] * 8, dtype=np.int16),
+              np.array([32767, -32768, 0], dtype=np.int16), np.repeat(np.array([3, 9], dtype=np.int16), 2048)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    new, win_off = _normalise_on_device(model.engine, reads)
+    for i, r in enumerate(reads):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = infer.normalize_raw_signal(r, "median").astype(np.float32)
+        got = new[win_off[i]:win_off[i + 1]].reshape(-1)
+        assert np.array_equal(got[:len(r)], want, equal_nan=True), (i, len(r))
+        assert np.all(got[len(r):] == 0), (i, len(r))
+    monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")
+    monkeypatch.setenv("CATFISH_INGEST_V1", "1")
+    old, _ = _normalise_on_device(model.engine, reads)
+    assert np.array_equal(old.view(np.uint32), new.view(np.uint32))                                # bit for bit, nan payloads included
+
+
+def test_bitmask_postprocess_kernel_matches_oracle_and_round_1_kernel(model, monkeypatch):
+    """postprocess_bits_kernel against the oracle's threshold + correct_short (catfish/infer.py:128-138, 174-198) per read and against
+    round 1's per-sample kernel bit for bit: many short reads (several per 64-sample word), runs of exactly min_run - 1 / min_run /
+    min_run + 1, runs that touch the end of a read and padding filled with ones right behind it, runs across word and chunk
+    (62-word) boundaries, a total that is not a multiple of 64, min_run 1 .. 64 and 65 (the fallback), other thresholds."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd import batching
+    rng = np.random.default_rng(5)
+    lens = [1, 2, 14, 15, 16, 29, 30, 31, 35, 36, 63, 64, 65, 70, 105, 127, 128, 129, 700, 3967, 3968, 3969, 4096, 8000, 12345] + \
+        rng.integers(1, 200, size=60).tolist()
+    sigs = [np.zeros(n) for n in lens]
+    pk = batching.pack_reads(sigs)
+    total = pk.n_windows * 35
+    dev = torch.device("cuda", 0)
+    offs, lengths = torch.from_numpy(pk.sample_offsets).to(dev), torch.from_numpy(pk.lengths).to(dev)
+    for min_run, threshold in ((15, 0.5), (1, 0.5), (2, 0.5), (16, 0.25), (33, 0.5), (64, 0.5), (65, 0.5), (14, 0.75)):
+        probs = np.ones(total, dtype=np.float32)                      # padding stays 1.0: it must still come out as 0
+        per_read = []
+        for i, n in enumerate(lens):
+            # runs of controlled lengths around min_run, separated by single zeros or longer gaps
+            p = np.zeros(n, dtype=np.float32)
+            pos = int(rng.integers(0, 3))
+            while pos < n:
+                run = int(rng.choice([1, min_run - 1, min_run, min_run + 1, 2 * min_run + 3, int(rng.integers(1, 90))]))
+                run = max(1, run)
+                p[pos:pos + run] = rng.uniform(threshold, 1.0, size=len(p[pos:pos + run]))
+                pos += run + int(rng.choice([1, 1, 2, 20]))
+            p[p == 0] = rng.uniform(0.0, threshold * 0.999, size=int((p == 0).sum()))
+            if i % 5 == 0:
+                p[-min(n, min_run + 2):] = 1.0                            # a run that ends with the read, ones in the padding behind it
+            per_read.append(p)
+            probs[pk.sample_offsets[i]:pk.sample_offsets[i] + n] = p
+        monkeypatch.delenv("CATFISH_INGEST_V1", raising=False)
+        new = model.engine.postprocess_device(torch.from_numpy(probs).to(dev), offs, lengths, threshold=threshold, min_run=min_run).cpu().numpy()
+        for i, n in enumerate(lens):
+            want = oracle.correct_short(oracle.class_from_threshold(per_read[i], threshold), min_run)
+            got = new[pk.sample_offsets[i]:pk.sample_offsets[i] + n]
+            assert np.array_equal(got, want), (min_run, i, n)
+            assert not new[pk.sample_offsets[i] + n:pk.sample_offsets[i + 1]].any(), (min_run, i)
+        monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")
+        monkeypatch.setenv("CATFISH_INGEST_V1", "1")
+        old = model.engine.postprocess_device(torch.from_numpy(probs).to(dev), offs, lengths, threshold=threshold, min_run=min_run).cpu().numpy()
+        assert np.array_equal(old, new), min_run
+    # a total that is not a multiple of 64 (the last word goes out byte by byte), all positive, one read
+    monkeypatch.delenv("CATFISH_INGEST_V1", raising=False)
+    for n in (1, 63, 65, 100, 64 * 62 + 7):
+        p = torch.ones(n, device=dev)
+        o = torch.tensor([0, n], dtype=torch.int64, device=dev)
+        ln = torch.tensor([n - (n > 20) * 3], dtype=torch.int64, device=dev)
+        got = model.engine.postprocess_device(p, o, ln).cpu().numpy()
+        real = int(ln.item())
+        assert got[:real].tolist() == ([1] * real if real >= 15 else [0] * real) and not got[real:].any(), n
