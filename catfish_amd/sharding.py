@@ -447,14 +447,23 @@ def run_sharded(signals, infer_fn, rank=None, world_size=None, gather_group=None
 
 
 # --------------------------------------------------------------------------- product path
-def _batches_by_samples(indices, lengths, max_samples):
-    """Consecutive groups of ``indices`` holding at most ``max_samples`` samples each (at least one read)."""
-    cur, tot = [], 0
+RAMP = (0.125, 0.375)      # the first batches of a file-driven shard, as fractions of the full batch (see _batches_by_samples)
+
+
+def _batches_by_samples(indices, lengths, max_samples, ramp=()):
+    """Consecutive groups of ``indices`` holding at most ``max_samples`` samples each (at least one read).
+
+    ``ramp``: fractions of ``max_samples`` that cap the FIRST batches instead -- a shard that starts from files has nothing on
+    the GPU until its first batch is read, staged and uploaded (1110 reads of 4096 samples: ~4 ms); with a first batch of an
+    eighth the device starts after ~0.5 ms and the loader thread has the next, larger batches ready before it runs dry.  Windows
+    are independent, so how reads are grouped never changes a result."""
+    cur, tot, k = [], 0, 0
     for i in indices:
         n = int(lengths[i])
-        if cur and tot + n > max_samples:
+        cap = max_samples * ramp[k] if k < len(ramp) else max_samples
+        if cur and tot + n > cap:
             yield cur
-            cur, tot = [], 0
+            cur, tot, k = [], 0, k + 1
         cur.append(i)
         tot += n
     if cur:
@@ -571,7 +580,7 @@ def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch,
     native loader straight into pinned memory instead of one Python call per file)."""
     runner = batch_runner if batch_runner is not None else EngineBatchRunner(model, max_samples_per_batch)
     if size_hints is not None and hasattr(runner, "run_files"):
-        path_batches = ([reads[i] for i in idx] for idx in _batches_by_samples(mine, size_hints, max_samples_per_batch))
+        path_batches = ([reads[i] for i in idx] for idx in _batches_by_samples(mine, size_hints, max_samples_per_batch, ramp=RAMP))
         if compact:
             return SpanTable.concat(list(runner.run_files(path_batches, compact=True)))
         out = []

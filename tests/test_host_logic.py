@@ -730,3 +730,22 @@ def test_torch_operator_is_registered_and_has_no_cpu_path():
     p2 = ops.pack_weights(rnn, n_layers=2, n_layers_res=0)
     b2, g2 = ops.unpack_weights(p2)
     assert g2["n_layers_res"] == 0 and sorted(b2) == sorted(ops.tensor_names(2, 0)) and b2[ops.tensor_names(2, 0)[0]].shape == (1 + 64, 128)
+
+
+def test_file_batches_ramp_up_and_cover_every_read_once():
+    """sharding._batches_by_samples: consecutive batches under the sample cap; with ``ramp`` the first batches are capped lower (the
+    device starts sooner on a shard that begins with reading files) and every read still appears exactly once, in order."""
+    from catfish_amd import sharding
+    lens = [4096] * 3000
+    plain = list(sharding._batches_by_samples(list(range(3000)), lens, 1120 * 4096))
+    assert [len(b) for b in plain] == [1120, 1120, 760]
+    ramped = list(sharding._batches_by_samples(list(range(3000)), lens, 1120 * 4096, ramp=sharding.RAMP))
+    assert [len(b) for b in ramped] == [140, 420, 1120, 1120, 200] and sum(ramped, []) == list(range(3000))
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 5000, size=400).tolist()
+    for ramp in ((), (0.125, 0.375), (0.001,)):
+        got = list(sharding._batches_by_samples(list(range(400)), lens, 40000, ramp=ramp))
+        assert sum(got, []) == list(range(400))
+        assert all(len(b) == 1 or sum(lens[i] for i in b) <= 40000 for b in got)
+    assert list(sharding._batches_by_samples([], [], 10, ramp=(0.5,))) == []
+    assert list(sharding._batches_by_samples([0], [99], 10, ramp=(0.5,))) == [[0]]          # a read longer than the cap still gets a batch
