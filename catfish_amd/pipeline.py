@@ -33,6 +33,9 @@ class ReadPipeline(object):
         self.dev = torch.device("cuda", engine.device)
         self.threshold = float(threshold)
         self.min_run = int(min_run)
+        # (All three streams at one priority: raising the forward pass's -- tried in round 5 -- starves the next batch's ingest until
+        # the running biGRU launch ends and serialises the two; the CLI's 131 072-window batches lost 8 %,
+        # profiles/r05_ab_pipeline_knobs.log.)
         self.compute = torch.cuda.Stream(self.dev)
         self.copy = torch.cuda.Stream(self.dev)
         self.down = torch.cuda.Stream(self.dev)
@@ -44,7 +47,6 @@ class ReadPipeline(object):
         # where the small kernels run: True = normalisation on the copy stream and post-processing on the download stream, beside
         # the neighbouring batches' forward passes; False = all kernels of a batch in order on the compute stream (only the
         # H2D / D2H copies overlap).  CATFISH_PIPE_OVERLAP=0/1 overrides (A/B knob for tools/).
-        import os
         if overlap_kernels is None and "CATFISH_PIPE_OVERLAP" in os.environ:
             overlap_kernels = os.environ["CATFISH_PIPE_OVERLAP"] != "0"
         self.overlap_kernels = True if overlap_kernels is None else bool(overlap_kernels)

@@ -448,6 +448,8 @@ def run_sharded(signals, infer_fn, rank=None, world_size=None, gather_group=None
 
 # --------------------------------------------------------------------------- product path
 RAMP = (0.125, 0.375)      # the first batches of a file-driven shard, as fractions of the full batch (see _batches_by_samples)
+if os.environ.get("CATFISH_DEBUG_KNOBS", "0") not in ("", "0") and os.environ.get("CATFISH_RAMP") == "0":
+    RAMP = ()                # A/B knob for tools/
 
 
 def _batches_by_samples(indices, lengths, max_samples, ramp=()):
