@@ -1790,7 +1790,8 @@ extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* re
     int rc = prof_begin(m, SLOT_POST, s, &pi);
     if (rc != CF_OK) return rc;
     const bool v1 = cf_knob("CATFISH_INGEST_V1") && atoi(cf_knob("CATFISH_INGEST_V1")) != 0;
-    if (v1 || min_run > 64) {                 // the bit-mask kernel's window covers runs of up to 64 samples (the reference uses 15)
+    // the bit-mask kernel's window covers runs of up to 64 samples (the reference uses 15) and it stores labels 16 bytes at a time
+    if (v1 || min_run > 64 || (reinterpret_cast<uintptr_t>(labels) & 15u) != 0) {
         hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, probs, read_offsets,
                            read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
     } else {

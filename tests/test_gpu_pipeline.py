@@ -1122,6 +1122,13 @@ def test_bitmask_postprocess_kernel_matches_oracle_and_round_1_kernel(model, mon
         monkeypatch.setenv("CATFISH_INGEST_V1", "1")
         old = model.engine.postprocess_device(torch.from_numpy(probs).to(dev), offs, lengths, threshold=threshold, min_run=min_run).cpu().numpy()
         assert np.array_equal(old, new), min_run
+    # a labels buffer that does not start on a 16-byte boundary (a view into a larger allocation): the C ABI takes any device pointer
+    monkeypatch.delenv("CATFISH_INGEST_V1", raising=False)
+    big = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+    for shift in (1, 3, 8):
+        view = big[shift:shift + total]
+        got = model.engine.postprocess_device(torch.from_numpy(probs).to(dev), offs, lengths, threshold=threshold, min_run=min_run, out=view)
+        assert np.array_equal(got.cpu().numpy(), new), shift
     # a total that is not a multiple of 64 (the last word goes out byte by byte), all positive, one read
     monkeypatch.delenv("CATFISH_INGEST_V1", raising=False)
     for n in (1, 63, 65, 100, 64 * 62 + 7):
