@@ -58,6 +58,8 @@ class ReadPipeline(object):
         self.stage_free = [torch.cuda.Event() for _ in range(self.depth)]
         self.tab = [None] * self.depth                           # pinned offset / length tables per staging slot
         self.k = 0
+        n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+        self._file_threads = max(2, min(8, n_cpu // 4))
 
     def _claim_slot(self):
         """The staging slot of the next batch, once the H2D copy that last read from it is done."""
@@ -67,7 +69,7 @@ class ReadPipeline(object):
         self.stage_free[slot].synchronize()                     # previous H2D out of this staging buffer is done
         return slot
 
-    def submit_files(self, paths, n_threads=4):
+    def submit_files(self, paths, n_threads=None):
         """Launch one batch straight from files: one-dimensional little-endian int16 ``.npy`` reads (the format
         ``infer.load_dac`` takes when there is no HDF5) are read by the library's host thread pool (``cf_load_npy_int16``)
         directly into the pinned staging slot -- no per-file Python, no intermediate arrays.  Returns a ticket, or None when
@@ -76,6 +78,11 @@ class ReadPipeline(object):
         paths = [os.fsencode(p) for p in paths]
         if not paths or not all(p.endswith(b".npy") for p in paths):      # infer.load_dac's own dispatch: only .npy takes this path
             return None
+        if n_threads is None:
+            # a quarter of the CPUs this rank owns (placement.bind: 32 per rank on an 8-GPU node), 2 .. 8: a 1110-file batch takes
+            # 6.8 / 2.3 / 1.8 / 1.7 ms with 1 / 4 / 8 / 16 threads (tools/exp_loader_threads.py) -- past 8 nothing is gained, and in
+            # bf16 the batch's forward pass takes 2.3 ms, so the loader sets the pace below that
+            n_threads = self._file_threads
         slot = self._claim_slot()
         blob = b"\x00".join(paths) + b"\x00"
         bounds = np.zeros(len(paths) + 1, dtype=np.int64)
