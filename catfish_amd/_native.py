@@ -105,6 +105,7 @@ SYMBOLS = {
     "cf_listing_sizes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
     "cf_listing_names": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "cf_listing_close": (None, [C.c_void_p]),
+    "cf_listing_load_npy_int16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     "cf_chunks_json": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64]),
     "cf_gru_pack_map": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),

@@ -73,8 +73,8 @@ static bool read_exact(int fd, unsigned char* dst, size_t n, size_t at) {
 
 // Header first: a directory, a FAST5, an .npz or a multi-gigabyte file of another kind is turned away after at most 4 KiB (its
 // header length, if it claims to be numpy) -- only a file whose header matches its size is read whole.
-static bool slurp(const char* path, Item& it) {
-    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+static bool slurp(int dirfd, const char* path, Item& it) {       // path relative to dirfd (AT_FDCWD: as open() takes it)
+    const int fd = openat(dirfd, path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return false;
     struct stat st;
     bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 12;
@@ -117,7 +117,7 @@ static void run_pool(int nt, F body) {
 
 }  // namespace cf_loader
 
-static int load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
+static int load_npy_int16(int dirfd, const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
                           int64_t* lengths, int64_t* total, int32_t n_threads) {
     if (n_files < 0 || capacity < 0) return fail(CF_ERR_INVALID, "cf_load_npy_int16: negative size");
     if (total) *total = 0;
@@ -132,7 +132,7 @@ static int load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t
             cf_loader::Item& it = items[(size_t)i];
             bool ok = false;
             try {
-                ok = cf_loader::slurp(paths + path_bounds[i], it);
+                ok = cf_loader::slurp(dirfd, paths + path_bounds[i], it);
             } catch (const std::bad_alloc&) {                   // a thread may not throw: remembered, reported as CF_ERR_NOMEM below
                 ok = false;
                 if (nomem[(size_t)t] < 0) nomem[(size_t)t] = i;
@@ -176,7 +176,7 @@ static int load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t
 extern "C" int cf_load_npy_int16(const char* paths, const int64_t* path_bounds, int64_t n_files, int16_t* out, int64_t capacity,
                                  int64_t* lengths, int64_t* total, int32_t n_threads) {
     try {
-        return load_npy_int16(paths, path_bounds, n_files, out, capacity, lengths, total, n_threads);
+        return load_npy_int16(AT_FDCWD, paths, path_bounds, n_files, out, capacity, lengths, total, n_threads);
     } catch (const std::bad_alloc&) {
         return fail(CF_ERR_NOMEM, "cf_load_npy_int16: out of host memory");
     } catch (const std::exception& e) {
@@ -408,5 +408,38 @@ extern "C" int cf_listing_from_names(const char* dir, const char* names, int64_t
         return fail(CF_ERR_NOMEM, "cf_listing_from_names: out of host memory");
     } catch (const std::exception& e) {
         return fail(CF_ERR_INVALID, std::string("cf_listing_from_names: ") + e.what());
+    }
+}
+
+// cf_load_npy_int16 for entries [lo, hi) of a listing: the names never leave the library (openat relative to the listing's directory),
+// so a rank of the CLI builds no path string per file at all.  Every entry must be named *.npy (infer.load_dac's own dispatch:
+// anything else is for the general loader) -- CF_ERR_INVALID names the first that is not, or that is not such an array.
+extern "C" int cf_listing_load_npy_int16(const cf_listing* l, int64_t lo, int64_t hi, int16_t* out, int64_t capacity, int64_t* lengths,
+                                         int64_t* total, int32_t n_threads) {
+    if (!listing_range_ok(l, lo, hi)) return fail(CF_ERR_INVALID, "cf_listing_load_npy_int16: bad range");
+    if (total) *total = 0;
+    if (hi == lo) return CF_OK;
+    int dfd = -1;
+    try {
+        const int64_t n = hi - lo;
+        std::vector<int64_t> bounds((size_t)n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            bounds[(size_t)i] = (int64_t)l->at[(size_t)(lo + i)];
+            const char* nm = l->blob.data() + bounds[(size_t)i];
+            const size_t len = strlen(nm);
+            if (len < 4 || memcmp(nm + len - 4, ".npy", 4) != 0)
+                return fail(CF_ERR_INVALID, std::string("cf_listing_load_npy_int16: not a .npy file: ") + nm);
+        }
+        dfd = open(l->dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+        if (dfd < 0) return fail(CF_ERR_INVALID, std::string("cf_listing_load_npy_int16: cannot open directory ") + l->dir + ": " + strerror(errno));
+        const int rc = load_npy_int16(dfd, l->blob.data(), bounds.data(), n, out, capacity, lengths, total, n_threads);
+        close(dfd);
+        return rc;
+    } catch (const std::bad_alloc&) {
+        if (dfd >= 0) close(dfd);
+        return fail(CF_ERR_NOMEM, "cf_listing_load_npy_int16: out of host memory");
+    } catch (const std::exception& e) {
+        if (dfd >= 0) close(dfd);
+        return fail(CF_ERR_INVALID, std::string("cf_listing_load_npy_int16: ") + e.what());
     }
 }

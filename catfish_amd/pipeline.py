@@ -99,6 +99,26 @@ class ReadPipeline(object):
         self.k += 1
         return self._launch(slot, lengths, int(total.value))
 
+    def submit_listing(self, listing, lo, hi, n_threads=None):
+        """``submit_files`` for entries [lo, hi) of a ``sharding.DirListing``: the library opens them relative to the listing's
+        directory (``cf_listing_load_npy_int16``), so not even a path string per file is built -- 12 500 files cost a rank 14 ms of
+        Python that way, a third of a bf16 shard's time.  None when the batch needs the general loader (an entry that is not a
+        ``.npy`` int16 vector, or reads that do not fit the staging buffer): nothing has been consumed then."""
+        if hi <= lo:
+            return None
+        slot = self._claim_slot()
+        lengths = np.empty(hi - lo, dtype=np.int64)
+        total = C.c_int64(0)
+        rc = self.eng._lib.cf_listing_load_npy_int16(listing._handle, int(lo), int(hi), C.c_void_p(self.stage[slot].data_ptr()), self.cap,
+                                                     lengths.ctypes.data_as(C.c_void_p), C.byref(total),
+                                                     int(self._file_threads if n_threads is None else n_threads))
+        if rc == N.CF_ERR_NOMEM:
+            N.check(rc)
+        if rc != N.CF_OK:
+            return None
+        self.k += 1
+        return self._launch(slot, lengths, int(total.value))
+
     def submit(self, dac_reads):
         """Launch one batch asynchronously; returns a ticket for ``collect``."""
         torch = self.torch

@@ -514,6 +514,27 @@ class EngineBatchRunner(object):
                     yield self._submit_reads([reads[i] for i in idx])
         return self._drive(items())
 
+    def run_listing(self, paths, ranges, compact=False):
+        """``run_files`` for index ranges of a ``ListingPaths``: batch [lo, hi) goes from the listing's directory into the pinned
+        staging buffer without a path string per file (``ReadPipeline.submit_listing``); a batch that needs the general loader is
+        handled like in ``run_files``, from the paths of just that batch."""
+        if getattr(self, "pipe", None) is None or type(self).run_files is not EngineBatchRunner.run_files:
+            # a runner that brings its own file handling (tests stand the oracle in for the engine): hand it the paths
+            return self.run_files(([paths[i] for i in range(lo, hi)] for lo, hi in ranges), compact)
+        self.compact = bool(compact)
+        from .infer import load_dac
+
+        def items():
+            for lo, hi in ranges:
+                ticket = self.pipe.submit_listing(paths.listing, lo, hi)
+                if ticket is not None:
+                    yield (ticket, None)
+                    continue
+                reads = [load_dac(paths[i]) for i in range(lo, hi)]
+                for idx in _batches_by_samples(list(range(len(reads))), [len(r) for r in reads], self.max_samples):
+                    yield self._submit_reads([reads[i] for i in idx])
+        return self._drive(items())
+
     def _submit_reads(self, reads):
         from . import batching
         from .infer import is_dac, normalize_raw_signal
@@ -581,6 +602,15 @@ def _spans_of_shard(model, reads, mine, lengths, load_fn, max_samples_per_batch,
     disk): ``reads`` are file names for ``infer.load_dac`` and the runner may read them itself (``run_files``: the library's
     native loader straight into pinned memory instead of one Python call per file)."""
     runner = batch_runner if batch_runner is not None else EngineBatchRunner(model, max_samples_per_batch)
+    if size_hints is not None and isinstance(reads, ListingPaths) and hasattr(runner, "run_listing"):
+        # contiguous indices of a native listing: the batches travel as (lo, hi), the names stay in the library
+        ranges = ((idx[0], idx[-1] + 1) for idx in _batches_by_samples(mine, size_hints, max_samples_per_batch, ramp=RAMP))
+        if compact:
+            return SpanTable.concat(list(runner.run_listing(reads, ranges, compact=True)))
+        out = []
+        for res in runner.run_listing(reads, ranges):
+            out.extend(res)
+        return out
     if size_hints is not None and hasattr(runner, "run_files"):
         path_batches = ([reads[i] for i in idx] for idx in _batches_by_samples(mine, size_hints, max_samples_per_batch, ramp=RAMP))
         if compact:
@@ -719,8 +749,6 @@ def chunk_files_local(model, paths, chunk_size=1000, max_samples_per_batch=None,
     if len(costs) != len(paths):
         raise ValueError("file_sizes must hold one size per path")
     mine = shard_contiguous(costs, world_size)[rank]
-    if lazy and mine:
-        paths.block(mine[0], mine[-1] + 1)
     from .batching import quiet_gc
     with quiet_gc():
         t0 = time.perf_counter()

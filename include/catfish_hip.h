@@ -238,6 +238,10 @@ int cf_listing_from_names(const char* dir, const char* names, int64_t n_bytes, i
 int cf_listing_sizes(const cf_listing* l, int64_t lo, int64_t hi, int64_t* sizes, int32_t n_threads);
 int cf_listing_names(const cf_listing* l, int64_t lo, int64_t hi, char* out, int64_t capacity, int64_t* bounds, int64_t* needed);
 void cf_listing_close(cf_listing* l);
+/* cf_load_npy_int16 for entries [lo, hi) of a listing, opened relative to the listing's directory: no path string per file is ever
+ * built by the caller.  Every entry must be named *.npy; same results, errors and buffers as cf_load_npy_int16. */
+int cf_listing_load_npy_int16(const cf_listing* l, int64_t lo, int64_t hi, int16_t* out, int64_t capacity, int64_t* lengths,
+                              int64_t* total, int32_t n_threads);
 
 /* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
  * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,

@@ -44,6 +44,8 @@ lib.cf_listing_names.restype = C.c_int
 lib.cf_listing_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, P64, P64]
 lib.cf_listing_from_names.restype = C.c_int
 lib.cf_listing_from_names.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+lib.cf_listing_load_npy_int16.restype = C.c_int
+lib.cf_listing_load_npy_int16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P16, C.c_int64, P64, P64, C.c_int32]
 lib.cf_listing_close.restype = None
 lib.cf_listing_close.argtypes = [C.c_void_p]
 CF_OK, CF_ERR_INVALID = 0, -1
@@ -170,6 +172,56 @@ def _fuzz_loader_in(box, cases, room, n_threads):
         assert total.value == total_want and list(lengths) == [len(w) for w in want]
         if total_want:
             assert np.array_equal(np.ctypeslib.as_array(out)[:total_want], np.concatenate(want))
+
+
+@settings(max_examples=max(20, int(os.environ.get("FUZZ_EXAMPLES", 250)) // 4), **SETTINGS)
+@given(st.lists(file_case(), min_size=1, max_size=6), st.sampled_from(["exact", "short", "roomy"]), st.integers(1, 8))
+def fuzz_listing_loader(cases, room, n_threads):
+    """cf_listing_load_npy_int16 over a whole directory of the loader fuzz's file kinds (named *.npy, read relative to the listing's
+    directory): same verdicts and bytes as numpy's reader, exactly-sized buffers."""
+    import shutil
+    import tempfile
+    box = tempfile.mkdtemp(dir=SCRATCH)
+    try:
+        names = []
+        for i, (kind, blob) in enumerate(cases):
+            if kind == "missing":
+                continue                                  # (a listing cannot hold a missing entry)
+            name = "c%d.npy" % i
+            if kind == "directory":
+                os.makedirs(os.path.join(box, name))
+            else:
+                with open(os.path.join(box, name), "wb") as fh:
+                    fh.write(blob)
+            names.append(name)
+        names.sort()
+        handle, n_entries = C.c_void_p(), C.c_int64(0)
+        assert lib.cf_listing_open(os.fsencode(box), C.byref(handle), C.byref(n_entries), None) == CF_OK
+        try:
+            assert n_entries.value == len(names)
+            want = [numpy_says(os.path.join(box, n)) for n in names]
+            good = all(w is not None for w in want)
+            total_want = sum(len(w) for w in want) if good else 0
+            cap = {"exact": total_want, "short": max(total_want - 1, 0), "roomy": total_want + 7}[room]
+            out = (C.c_int16 * max(cap, 1))()
+            lengths = (C.c_int64 * max(len(names), 1))()
+            total = C.c_int64(-5)
+            rc = lib.cf_listing_load_npy_int16(handle, 0, len(names), out if cap else None, cap, lengths, C.byref(total), n_threads)
+            if not names:
+                assert rc == CF_OK and total.value == 0
+            elif not good:
+                assert rc == CF_ERR_INVALID, (rc, [k for k, _ in cases])
+            elif cap < total_want:
+                assert rc == CF_ERR_INVALID and total.value == total_want
+            else:
+                assert rc == CF_OK, (rc, lib.cf_last_error())
+                assert total.value == total_want and list(lengths)[:len(names)] == [len(w) for w in want]
+                if total_want:
+                    assert np.array_equal(np.ctypeslib.as_array(out)[:total_want], np.concatenate(want))
+        finally:
+            lib.cf_listing_close(handle)
+    finally:
+        shutil.rmtree(box, ignore_errors=True)
 
 
 # ------------------------------------------------------------------------------------ cf_chunks_from_spans / cf_chunks_json
@@ -384,4 +436,5 @@ if __name__ == "__main__":
     fuzz_chunks()
     fuzz_stat()
     fuzz_listing()
+    fuzz_listing_loader()
     print("fuzz ok")

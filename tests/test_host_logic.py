@@ -749,3 +749,54 @@ def test_file_batches_ramp_up_and_cover_every_read_once():
         assert all(len(b) == 1 or sum(lens[i] for i in b) <= 40000 for b in got)
     assert list(sharding._batches_by_samples([], [], 10, ramp=(0.5,))) == []
     assert list(sharding._batches_by_samples([0], [99], 10, ramp=(0.5,))) == [[0]]          # a read longer than the cap still gets a batch
+
+
+def test_native_loader_reads_a_listing_block_without_path_strings(tmp_path):
+    """cf_listing_load_npy_int16 (``DirListing`` entries [lo, hi) opened relative to the listing's directory) against ``infer.load_dac``
+    on the same files: same samples, same lengths, in listing order; a block holding an entry that is not named ``*.npy`` or is not an
+    int16 vector is refused with the entry named -- the caller then takes the general loader for that batch."""
+    import ctypes as C
+    from catfish_amd import _native as N, infer, sharding
+    d = tmp_path / "reads"
+    d.mkdir()
+    rng = np.random.default_rng(2)
+    want = {}
+    for i, n in enumerate([4096, 1, 0, 35, 700, 12345, 2, 999]):
+        name = "read_%03d.npy" % (7 * i % 8)
+        np.save(d / name, rng.integers(-3000, 3000, size=n).astype(np.int16))
+        want[name] = infer.load_dac(str(d / name))
+    lst = sharding.DirListing(str(d))
+    names = lst.names()
+    assert names == sorted(want)
+    lib = N.lib()
+
+    def load(lo, hi, cap, threads=3):
+        out = np.full(max(cap, 1), -7, dtype=np.int16)
+        lengths = np.full(max(hi - lo, 1), -1, dtype=np.int64)
+        total = C.c_int64(-1)
+        rc = lib.cf_listing_load_npy_int16(lst._handle, lo, hi, out.ctypes.data_as(C.c_void_p), cap, lengths.ctypes.data_as(C.c_void_p),
+                                           C.byref(total), threads)
+        return rc, out, lengths[:hi - lo], total.value
+
+    everything = np.concatenate([want[n] for n in names])
+    rc, out, lengths, total = load(0, len(names), len(everything))
+    assert rc == 0 and total == len(everything) and lengths.tolist() == [len(want[n]) for n in names]
+    assert np.array_equal(out[:total], everything)
+    rc, out, lengths, total = load(2, 5, 20000, threads=1)
+    assert rc == 0 and np.array_equal(out[:total], np.concatenate([want[n] for n in names[2:5]]))
+    assert load(3, 3, 0)[0] == 0 and load(3, 3, 0)[3] == 0
+    rc, _out, _l, total = load(0, len(names), len(everything) - 1)                      # does not fit: refused, the need reported
+    assert rc == N.CF_ERR_INVALID and total == len(everything)
+    assert load(0, len(names) + 1, 10)[0] == N.CF_ERR_INVALID                            # range off the end
+    np.save(d / "read_100.npy", np.zeros((2, 3), np.int16))                              # not a vector
+    (d / "notes.txt").write_text("hello")                                                # not a .npy
+    lst2 = sharding.DirListing(str(d))
+    n2 = lst2.names()
+    total = C.c_int64(0)
+    for bad in ("read_100.npy", "notes.txt"):
+        k = n2.index(bad)
+        out = np.zeros(64, np.int16)
+        lengths = np.zeros(1, np.int64)
+        rc = lib.cf_listing_load_npy_int16(lst2._handle, k, k + 1, out.ctypes.data_as(C.c_void_p), 64, lengths.ctypes.data_as(C.c_void_p),
+                                           C.byref(total), 2)
+        assert rc == N.CF_ERR_INVALID and bad.encode() in lib.cf_last_error()
