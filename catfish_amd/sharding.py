@@ -249,6 +249,12 @@ def stat_sizes(directory, names, n_threads=4):
     return sizes
 
 
+def _host_threads():
+    """Threads for the library's host pools (stat, file reads): a quarter of the CPUs this rank owns (``placement.bind``), 2 .. 8."""
+    n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+    return max(2, min(8, n_cpu // 4))
+
+
 def shared_listing(input_dir, rank=0, world_size=1, group=None, error=None):
     """The listing step of the sharded per-file loop (catfish/catfish:49-50 lists the directory once, in one process) ->
     ``(listing, sizes)``: a ``DirListing`` over ALL entries in one order and their int64 sizes on disk, the same on every rank.
@@ -274,7 +280,7 @@ def shared_listing(input_dir, rank=0, world_size=1, group=None, error=None):
     if not distributed:
         if error is not None:
             raise error
-        return listing, listing.sizes(0, len(listing))
+        return listing, listing.sizes(0, len(listing), n_threads=_host_threads())
     box = [None]
     if rank == 0:
         box[0] = ("error", "%s: %s" % (type(error).__name__, error)) if error is not None else (len(listing), listing.names_blob())
@@ -285,7 +291,7 @@ def shared_listing(input_dir, rank=0, world_size=1, group=None, error=None):
             if rank != 0:
                 listing = DirListing.from_names_blob(input_dir, box[0][1], box[0][0])
             lo, hi = rank * len(listing) // world_size, (rank + 1) * len(listing) // world_size
-            sizes = listing.sizes(lo, hi)
+            sizes = listing.sizes(lo, hi, n_threads=_host_threads())
         except Exception as exc:              # noqa: BLE001
             error = exc
     said = [None] * dist.get_world_size()
