@@ -119,6 +119,49 @@ class ReadPipeline(object):
         self.k += 1
         return self._launch(slot, lengths, int(total.value))
 
+    # ---- the same with the file reads one batch AHEAD, in a helper thread (the native call releases the GIL): while the main thread
+    # waits for the GPU and assembles the results of the batch before, the next batch's files are read into the other staging slot.
+    # In bf16 a 1110-read batch takes the GPU 2.3 ms and its files 2.1 ms to read: back to back on one thread the host set the pace.
+    def preload_listing(self, listing, lo, hi, n_threads=None):
+        """Start reading entries [lo, hi) of ``listing`` into the staging slot the NEXT launch will use; -> a handle for
+        ``launch_preloaded``.  At most one preload may be pending, and nothing else may be submitted until it has been launched or
+        dropped (``drop_preloaded``): the caller is ``EngineBatchRunner.run_listing``."""
+        import concurrent.futures
+        if getattr(self, "_loader", None) is None:
+            self._loader = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="catfish-files")
+        slot = self.k % self.depth
+        stage, cap = self.stage[slot], self.cap
+        threads = int(self._file_threads if n_threads is None else n_threads)
+        lib, handle, free = self.eng._lib, listing._handle, self.stage_free[slot]
+
+        def work():
+            free.synchronize()                                   # the H2D copy that last read from this staging buffer is done
+            lengths = np.empty(max(0, hi - lo), dtype=np.int64)
+            total = C.c_int64(0)
+            rc = lib.cf_listing_load_npy_int16(handle, int(lo), int(hi), C.c_void_p(stage.data_ptr()), cap,
+                                               lengths.ctypes.data_as(C.c_void_p), C.byref(total), threads)
+            return rc, lengths, int(total.value)
+        return (slot, self._loader.submit(work))
+
+    def launch_preloaded(self, pre):
+        """Launch the batch ``preload_listing`` read.  None when it needs the general loader (nothing has been consumed)."""
+        slot, fut = pre
+        rc, lengths, total = fut.result()
+        if rc == N.CF_ERR_NOMEM:
+            N.check(rc)
+        if rc != N.CF_OK or len(lengths) == 0:
+            return None
+        if slot != self.k % self.depth or self.inflight[slot] is not None:
+            raise RuntimeError("ReadPipeline: a preloaded batch must be launched before anything else is submitted")
+        self.k += 1
+        return self._launch(slot, lengths, total)
+
+    @staticmethod
+    def drop_preloaded(pre):
+        """Wait for a preload that will not be launched (its staging slot is reusable afterwards)."""
+        if pre is not None:
+            pre[1].result()
+
     def submit(self, dac_reads):
         """Launch one batch asynchronously; returns a ticket for ``collect``."""
         torch = self.torch
