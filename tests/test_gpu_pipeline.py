@@ -1138,3 +1138,60 @@ def test_bitmask_postprocess_kernel_matches_oracle_and_round_1_kernel(model, mon
         got = model.engine.postprocess_device(p, o, ln).cpu().numpy()
         real = int(ln.item())
         assert got[:real].tolist() == ([1] * real if real >= 15 else [0] * real) and not got[real:].any(), n
+
+
+def test_cli_directory_of_mixed_formats_and_many_batches(tmp_path, ckpt_weights):
+    """`cli.run_pipeline` over a directory the native listing path cannot take whole: int16 ``.npy`` vectors (the fast path: listing
+    ranges, files preloaded by the helper thread), an ``.npz`` (key ``raw``), a headerless ``.bin``, an ``.npy`` holding int32 codes
+    and one holding an already NORMALISED float trace -- batches that contain one of those fall back to ``infer.load_dac`` (and the
+    float read to the host normalisation branch) while their neighbours stay on the fast path; a small pass capacity forces many
+    batches, ramped first.  Every read must equal the per-read oracle, in the listing's (bytewise) order (catfish/catfish:50-82)."""
+    import contextlib
+    import io
+    import json
+    from catfish_amd import cli, sharding
+    net = _write_model_dir(tmp_path, ckpt_weights)
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    raw = {}
+    for i in range(34):
+        d = oracle.synthetic_dac(1, 600 + 97 * (i % 9), seed=700 + i)[0]
+        name = "read_%02d.npy" % i
+        if i == 5:
+            name = "read_05.npz"
+            np.savez(reads / name, raw=d)
+        elif i == 11:
+            name = "read_11.bin"
+            d.astype("<i2").tofile(reads / name)
+        elif i == 20:
+            np.save(reads / name, d.astype(np.int32))                          # integer codes of another width: still a DAC read
+        elif i == 27:
+            np.save(reads / name, oracle.normalize_raw_signal(d))               # float64: normalised once more on the host, like load_raw would
+        else:
+            np.save(reads / name, d)
+        raw[name] = d
+    orig = sharding.RAMP
+    timings = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = cli.run_pipeline(str(reads), str(tmp_path / "out"), chunk_size=300, network_path=str(net), device=0, timings=timings,
+                               gather_table=True)
+    assert sharding.RAMP == orig and res["reads"] == 34 and res["files"] == sorted(raw)
+    hp = json.load(open(tmp_path / "out" / "TEMP" / "hp_positions.json"))
+    nonhp = json.load(open(tmp_path / "out" / "TEMP" / "nonhp_positions.json"))
+    assert list(nonhp) == sorted(raw)                                           # one rank: the documents follow the listing's order
+    for name, d in raw.items():
+        sig = oracle.normalize_raw_signal(d)
+        if name == "read_27.npy":
+            sig = oracle.normalize_raw_signal(sig)
+        spans, length, _ = oracle.infer_read(sig, ckpt_weights, np.float32)
+        merged, non = cli.chunks_of_read([list(s) for s in spans], length, 300)
+        assert hp.get(name) == merged and nonhp[name] == json.loads(json.dumps(non)), name
+    # the same directory in batches of a few reads each (ramped 1/8, 3/8, then full): same documents
+    from catfish_amd import neural_network
+    model = neural_network.load_network("ResNetRNN", str(net), checkpoint=30000, device=0, max_windows_per_pass=256)
+    listing, sizes = sharding.shared_listing(str(reads))
+    mine, table = sharding.chunk_files_local(model, sharding.ListingPaths(listing), 300, max_samples_per_batch=256 * 35, rank=0, world_size=1,
+                                             file_sizes=sizes)
+    assert mine == list(range(34))
+    hp2, non2 = table.to_dicts(listing.names())
+    assert json.loads(json.dumps(hp2)) == hp and json.loads(json.dumps(non2)) == nonhp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the round-5 measurements the docs cite, written under gpurun_out/round5/ (copy what is judged into profiles/).
-# usage:  bash tools/collect_round5.sh <commit> [stage ...]     stages: probe tests bench rehearse prof x3abl (default: all but x3abl)
+# usage:  bash tools/collect_round5.sh <commit> [stage ...]     stages: probe tests bench rehearse prof clip ingest x3abl (default: probe tests bench rehearse prof)
 COMMIT=${1:-unknown}; shift
 STAGES=${@:-probe tests bench rehearse prof}
 ROOT="$GRAFT_REPO_ROOT"
@@ -22,6 +22,10 @@ for S in $STAGES; do
     x3abl)   # upper bounds for the bf16x3 layer-0 experiment: timing-only ablations, interleaved rounds on one box
       bash tools/ab_x3_variants.sh 2 default tools/x3var/libcatfish_x3_abl4.so tools/x3var/libcatfish_x3_abl1.so tools/x3var/libcatfish_x3_abl2.so \
         > $OUT/x3_layer0_ablation.log 2>&1 ;;
+    clip)    # the CLI by precision + the file pool by thread count
+      TMPDIR=/tmp python tools/exp_loader_threads.py 2>&1 | grep -v amdgpu.ids > $OUT/cli_by_precision.log ;;
+    ingest)  # standalone times of the ingest / post-processing kernels, round 5 against round 1
+      python tools/exp_ingest_post.py > $OUT/ingest_post_kernels.log 2>&1 ;;
     prof)
       for P in fp32 bf16 bf16x3; do
         rm -rf /tmp/kt_$P
