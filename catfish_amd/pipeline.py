@@ -61,6 +61,18 @@ class ReadPipeline(object):
         n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
         self._file_threads = max(2, min(8, n_cpu // 4))
 
+    def close(self):
+        """Stop the helper thread of ``preload_listing`` (if one was started); the pipeline must not be used afterwards."""
+        loader, self._loader = getattr(self, "_loader", None), None
+        if loader is not None:
+            loader.shutdown(wait=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _claim_slot(self):
         """The staging slot of the next batch, once the H2D copy that last read from it is done."""
         slot = self.k % self.depth
