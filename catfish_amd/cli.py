@@ -13,7 +13,6 @@ is not installed the chunk coordinates are written as JSON next to the would-be 
 from __future__ import annotations
 
 import datetime
-import json
 import os
 
 from . import infer
