@@ -74,7 +74,7 @@ def chunks_of_read(hp_positions, len_read, chunk_size=1000):
 
 
 def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN", network_type="ResNetRNN",
-                 checkpoint=30000, device=None, precision="fp32", timings=None, gather_table=False):
+                 checkpoint=30000, device=None, precision="fp32", timings=None, gather_table=False, bind=True):
     """Body of the reference's ``main`` (catfish/catfish:23-94) up to the split step.
 
     Under ``torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the per-file loop of
@@ -92,14 +92,18 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
     (``table.to_dicts(files)`` = the reference's ``hp_dict`` / ``nonhp_dict``).  ``timings`` (optional dict) receives
     this rank's ``listing_s`` (output directories, the directory listing and the ranks' agreement on it), ``model_s`` (network
     load up to the ranks' agreement on it), ``setup_s`` (their sum), ``infer_s``, ``chunks_s``, ``write_s`` and ``placement``
-    (the CPUs the rank bound itself to, ``placement.summary``).
+    (the CPUs the rank bound itself to, ``placement.summary``).  ``bind``: bind this PROCESS to the CPUs next to the rank's GPU before
+    the first GPU call (``catfish_amd/placement.py``; process-wide and permanent, like a ``taskset`` around the job -- pass False when
+    the caller manages affinity itself).
     """
     import time
     from . import chunks, placement, sharding
     rank, world, local_rank = sharding.dist_env()
     # before the first GPU call and the first pinned allocation: this rank, its loader thread and the library's file pool run
     # on the CPUs next to its MI355X (a no-op when the caller -- bench.py -- bound the process already)
-    place = placement.bind(local_rank, device_of_rank=(lambda r: _pick_device(r) if (device is None or r != local_rank) else device))
+    # (``bind=False``, or CATFISH_BIND=0, for a caller that manages its process's affinity itself: the binding is process-wide and stays)
+    place = placement.bind(local_rank, device_of_rank=(lambda r: _pick_device(r) if (device is None or r != local_rank) else device)) \
+        if bind else {"bound": False, "source": "off (bind=False)", "cpus": sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []}
     own_group = sharding.init_host_group()
     timings = {} if timings is None else timings
     timings["placement"] = placement.summary(place)
