@@ -1195,3 +1195,36 @@ def test_cli_directory_of_mixed_formats_and_many_batches(tmp_path, ckpt_weights)
     assert mine == list(range(34))
     hp2, non2 = table.to_dicts(listing.names())
     assert json.loads(json.dumps(hp2)) == hp and json.loads(json.dumps(non2)) == nonhp
+
+
+def test_file_driven_shard_at_scale_is_invariant_to_batching(tmp_path, model):
+    """The file-driven path behind the CLI at a size the oracle cannot follow: 1500 files of 1 .. 40 000 samples (log-uniform: reads
+    below a window, reads past the ingest kernel's register classes at 4096 and 16 384, a few beyond the staging buffer's estimate),
+    through ``chunk_files_local`` over a native listing -- listing ranges, ramped batches cut by padded samples, the files of batch
+    k + 1 preloaded by the helper thread, oversize batches re-cut -- against ``batching.infer_reads_dac`` on the same reads loaded in
+    Python and packed by length buckets.  Windows are independent, so the spans of every read must be IDENTICAL whichever way the
+    reads were grouped, staged and launched; a read dropped, duplicated or shifted by any of that machinery shows here."""
+    from catfish_amd import batching, chunks, infer, sharding
+    rng = np.random.default_rng(17)
+    lens = np.rint(np.exp(rng.uniform(0, np.log(40000), size=1500))).astype(int)
+    lens[:6] = [1, 34, 35, 36, 4096, 16384]
+    d = tmp_path / "reads"
+    d.mkdir()
+    for i, n in enumerate(lens):
+        np.save(d / ("r%05d.npy" % ((i * 7919) % 100000)), oracle.synthetic_dac(1, max(int(n), 2), seed=3000 + i)[0][:int(n)])
+    listing, sizes = sharding.shared_listing(str(d))
+    names = listing.names()
+    assert len(names) == 1500
+    mine, table = sharding.chunk_files_local(model, sharding.ListingPaths(listing), 1000, max_samples_per_batch=8192 * 35, rank=0,
+                                             world_size=1, file_sizes=sizes)
+    assert mine == list(range(1500)) and len(table) == 1500
+    reads = [infer.load_dac(str(d / n)) for n in names]
+    want = batching.infer_reads_dac(model, reads, max_windows=4096)
+    assert [int(x) for x in table.lengths] == [len(r) for r in reads] == [w[1] for w in want]
+    bounds = np.concatenate(([0], np.cumsum([len(w[0]) for w in want])))
+    flat = np.array([s for w in want for s in w[0]], dtype=np.int64).reshape(-1, 2)
+    ref = chunks.ChunkTable.from_spans(bounds, flat[:, 0], flat[:, 1], [w[1] for w in want], 1000)
+    for a, b in ((table.hp_bounds, ref.hp_bounds), (table.hp_start, ref.hp_start), (table.hp_end, ref.hp_end),
+                 (table.nonhp_bounds, ref.nonhp_bounds), (table.nonhp_start, ref.nonhp_start), (table.nonhp_end, ref.nonhp_end)):
+        assert np.array_equal(a, b)
+    assert int(table.has_hp.sum()) > 100                                                   # (the comparison is not vacuous)
