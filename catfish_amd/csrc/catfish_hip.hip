@@ -1796,9 +1796,44 @@ extern "C" int cf_postprocess(cf_model* m, const float* probs, const int64_t* re
                            read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
     } else {
         const int64_t n_words = (total_samples + 63) / 64, n_chunks = (n_words + CF_POST_WORDS - 1) / CF_POST_WORDS;
-        hipLaunchKernelGGL(postprocess_bits_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, probs, read_offsets,
-                           read_lengths, n_reads, total_samples, threshold, (int)min_run, labels);
+        hipLaunchKernelGGL(postprocess_bits_kernel<false>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, probs, read_offsets,
+                           read_lengths, n_reads, total_samples, threshold, (int)min_run, labels, (int64_t)0, (int64_t*)nullptr,
+                           (int64_t*)nullptr, (unsigned long long*)nullptr);
     }
+    HIP_TRY(hipGetLastError());
+    return prof_end(m, s, pi);
+}
+
+// cf_postprocess + cf_spans as ONE launch ("one segmented-scan kernel returning spans"): the corrected labels' run
+// boundaries come straight from the bit masks; labels may be NULL when only the spans are wanted (the streaming pipeline).
+extern "C" int cf_postprocess_spans(cf_model* m, const float* probs, const int64_t* read_offsets, const int64_t* read_lengths,
+                                    int64_t n_reads, int64_t total_samples, float threshold, int32_t min_run, uint8_t* labels,
+                                    int64_t max_runs, int64_t* starts, int64_t* ends, uint64_t* counts, void* stream) {
+    if (!m) return fail(CF_ERR_INVALID, "cf_postprocess_spans: null model");
+    if (n_reads < 0 || total_samples < 0 || max_runs < 0) return fail(CF_ERR_INVALID, "cf_postprocess_spans: negative size");
+    if (!counts) return fail(CF_ERR_INVALID, "cf_postprocess_spans: null counts");
+    if (min_run < 1) return fail(CF_ERR_INVALID, "cf_postprocess_spans: min_run must be >= 1");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(uint64_t), s));
+    if (n_reads == 0 || total_samples == 0) return CF_OK;
+    if (!probs || !read_offsets || !read_lengths || (max_runs > 0 && (!starts || !ends)))
+        return fail(CF_ERR_INVALID, "cf_postprocess_spans: null buffer");
+    const bool v1 = cf_knob("CATFISH_INGEST_V1") && atoi(cf_knob("CATFISH_INGEST_V1")) != 0;
+    if (v1 || min_run > 64 || (reinterpret_cast<uintptr_t>(labels) & 15u) != 0) {
+        // what the bit-mask kernel does not cover goes through the two calls it replaces (they need a labels buffer)
+        if (!labels) return fail(CF_ERR_INVALID, "cf_postprocess_spans: min_run > 64 needs a labels buffer");
+        const int rc = cf_postprocess(m, probs, read_offsets, read_lengths, n_reads, total_samples, threshold, min_run, labels, stream);
+        if (rc != CF_OK) return rc;
+        return cf_spans(m, labels, total_samples, max_runs, starts, ends, counts, stream);
+    }
+    size_t pi = 0;
+    int rc = prof_begin(m, SLOT_POST, s, &pi);
+    if (rc != CF_OK) return rc;
+    const int64_t n_words = (total_samples + 63) / 64, n_chunks = (n_words + CF_POST_WORDS - 1) / CF_POST_WORDS;
+    hipLaunchKernelGGL(postprocess_bits_kernel<true>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, probs, read_offsets, read_lengths,
+                       n_reads, total_samples, threshold, (int)min_run, labels, max_runs, starts, ends,
+                       reinterpret_cast<unsigned long long*>(counts));
     HIP_TRY(hipGetLastError());
     return prof_end(m, s, pi);
 }

@@ -170,9 +170,17 @@ __device__ __forceinline__ cf_w192 w192_shl(const cf_w192& x, int s) {     // to
     return {x.p << s, (x.m << s) | (x.p >> (64 - s)), (x.n << s) | (x.m >> (64 - s))};
 }
 
+// SPANS: the run boundaries of the corrected labels leave with the same launch (cf_postprocess_spans: the "one kernel returning
+// spans" of SURVEY.md 8f-1) -- a run starts where a bit is set and its lower neighbour is not, m & ~(m << 1), and ends likewise;
+// the neighbours across the word's edges are the final bits 63 / 0 of the window's outer words, which are exact (see above: what is
+// incomplete there never comes within min_run - 1 bits of the middle word).  A wave reserves room for all its boundaries with one
+// global atomic per list (prefix sums of the lanes' popcounts), like spans_kernel; labels may then be NULL (not written at all).
+template <bool SPANS>
 __global__ __launch_bounds__(256) void postprocess_bits_kernel(const float* __restrict__ probs, const int64_t* __restrict__ read_offsets,
                                                                const int64_t* __restrict__ read_lengths, int64_t n_reads, int64_t total,
-                                                               float threshold, int min_run, uint8_t* __restrict__ labels) {
+                                                               float threshold, int min_run, uint8_t* __restrict__ labels, int64_t max_runs,
+                                                               int64_t* __restrict__ starts, int64_t* __restrict__ ends,
+                                                               unsigned long long* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_words = (total + 63) >> 6;
@@ -233,8 +241,45 @@ __global__ __launch_bounds__(256) void postprocess_bits_kernel(const float* __re
         const cf_w192 s = w192_shl(x, min_run - have);
         x = {x.p | s.p, x.m | s.m, x.n | s.n};
     }
+    const bool payload = lane != 0 && lane != 63 && base < total;
+    if constexpr (SPANS) {
+        unsigned long long sm = 0, em = 0;
+        if (payload) {
+            sm = x.m & ~((x.m << 1) | (x.p >> 63));
+            em = x.m & ~((x.m >> 1) | (x.n << 63));
+        }
+        const unsigned cs = (unsigned)__popcll(sm), ce = (unsigned)__popcll(em);
+        unsigned ps = cs, pe = ce;                                         // inclusive prefix sums over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned os = (unsigned)__shfl_up((int)ps, d), oe = (unsigned)__shfl_up((int)pe, d);
+            if (lane >= d) { ps += os; pe += oe; }
+        }
+        const unsigned ts = (unsigned)__shfl((int)ps, 63), te = (unsigned)__shfl((int)pe, 63);
+        unsigned long long bs = 0, be = 0;
+        if (lane == 0) {
+            if (ts) bs = atomicAdd(&counts[0], (unsigned long long)ts);
+            if (te) be = atomicAdd(&counts[1], (unsigned long long)te);
+        }
+        bs = (unsigned long long)__shfl((long long)bs, 0);
+        be = (unsigned long long)__shfl((long long)be, 0);
+        unsigned long long k = bs + ps - cs;
+        while (sm) {
+            const int b = __builtin_ctzll(sm);
+            sm &= sm - 1;
+            if ((int64_t)k < max_runs) starts[k] = base + b;
+            ++k;
+        }
+        k = be + pe - ce;
+        while (em) {
+            const int b = __builtin_ctzll(em);
+            em &= em - 1;
+            if ((int64_t)k < max_runs) ends[k] = base + b + 1;             // exclusive, like spans_kernel
+            ++k;
+        }
+    }
     // 4. the middle word as label bytes
-    if (lane == 0 || lane == 63 || base >= total) return;
+    if (!payload || labels == nullptr) return;
     const unsigned long long bits = x.m;
     if (base + 64 <= total) {
         uint4* dst = reinterpret_cast<uint4*>(labels + base);              // base is a multiple of 64, labels a device allocation: 16-byte aligned

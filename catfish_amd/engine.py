@@ -160,6 +160,42 @@ class HipEngine(object):
                                          C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream)))
         return out
 
+    def postprocess_spans_device(self, probs, read_offsets, read_lengths, threshold=0.5, min_run=15, max_runs=None, labels=False,
+                                 stream=None):
+        """``postprocess_device`` + ``spans_device`` as ONE launch (``cf_postprocess_spans``) -> (starts, ends) numpy int64, sorted
+        ascending (packed positions; ends exclusive), and the uint8 CUDA labels as a third value when ``labels=True``."""
+        import torch
+        if not probs.is_cuda or probs.dtype != torch.float32 or not probs.is_contiguous():
+            raise ValueError("probs must be a contiguous float32 CUDA tensor")
+        for t in (read_offsets, read_lengths):
+            if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("read_offsets/read_lengths must be contiguous int64 CUDA tensors")
+        n_reads, total = int(read_lengths.numel()), int(probs.numel())
+        if int(read_offsets.numel()) != n_reads + 1:
+            raise ValueError("read_offsets must have n_reads + 1 entries")
+        if max_runs is None:
+            max_runs = total // max(1, int(min_run)) + 16
+        dev = probs.device
+        lab = torch.empty(total, dtype=torch.uint8, device=dev) if (labels or int(min_run) > 64) else None
+        starts = torch.empty(max_runs, dtype=torch.int64, device=dev)
+        ends = torch.empty(max_runs, dtype=torch.int64, device=dev)
+        counts = torch.empty(2, dtype=torch.int64, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        N.check(self._lib.cf_postprocess_spans(self._handle, C.c_void_p(probs.data_ptr()), C.c_void_p(read_offsets.data_ptr()),
+                                               C.c_void_p(read_lengths.data_ptr()), n_reads, total, float(threshold), int(min_run),
+                                               C.c_void_p(lab.data_ptr()) if lab is not None else None, int(max_runs),
+                                               C.c_void_p(starts.data_ptr()), C.c_void_p(ends.data_ptr()), C.c_void_p(counts.data_ptr()),
+                                               C.c_void_p(stream.cuda_stream)))
+        n_s, n_e = (int(v) for v in counts.cpu().tolist())      # synchronises the stream
+        self.check_error()
+        if n_s != n_e:
+            raise RuntimeError("cf_postprocess_spans: %d run starts but %d run ends" % (n_s, n_e))
+        if n_s > max_runs:
+            return self.postprocess_spans_device(probs, read_offsets, read_lengths, threshold, min_run, n_s, labels, stream)
+        out = (np.sort(starts[:n_s].cpu().numpy()), np.sort(ends[:n_e].cpu().numpy()))
+        return out + (lab,) if labels else out
+
     def spans_device(self, labels, max_runs=None, stream=None):
         """Device run-length pass over corrected labels -> (starts, ends) numpy int64, sorted ascending
         (packed positions; ends exclusive).  Only the two short lists cross PCIe."""

@@ -243,15 +243,19 @@ class ReadPipeline(object):
             infer_done.record(self.compute)
         with torch.cuda.stream(k_post):                          # overlap mode: post-processing overlaps the next batch's forward pass
             k_post.wait_event(infer_done)
-            labels = self.eng.postprocess_device(probs, d_soff, d_len, threshold=self.threshold, min_run=self.min_run,
-                                                 stream=k_post)
+            # threshold + correct_short + run boundaries in ONE launch, straight from the probabilities; the labels themselves are
+            # never written (cf_postprocess_spans with labels = NULL) -- except for min_run > 64, which takes the two older kernels
             max_runs = n_windows * WINDOW_SIZE // self.min_run + 16
+            total = n_windows * WINDOW_SIZE
+            labels = torch.empty(total, dtype=torch.uint8, device=self.dev) if self.min_run > 64 else None
             t.starts = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
             t.ends = torch.empty(max_runs, dtype=torch.int64, device=self.dev)
             t.counts = torch.empty(2, dtype=torch.int64, device=self.dev)
-            N.check(self.eng._lib.cf_spans(self.eng._handle, C.c_void_p(labels.data_ptr()), int(labels.numel()), max_runs,
-                                           C.c_void_p(t.starts.data_ptr()), C.c_void_p(t.ends.data_ptr()),
-                                           C.c_void_p(t.counts.data_ptr()), C.c_void_p(k_post.cuda_stream)))
+            N.check(self.eng._lib.cf_postprocess_spans(
+                self.eng._handle, C.c_void_p(probs.data_ptr()), C.c_void_p(d_soff.data_ptr()), C.c_void_p(d_len.data_ptr()), n_reads, total,
+                float(self.threshold), int(self.min_run), C.c_void_p(labels.data_ptr()) if labels is not None else None, max_runs,
+                C.c_void_p(t.starts.data_ptr()), C.c_void_p(t.ends.data_ptr()), C.c_void_p(t.counts.data_ptr()),
+                C.c_void_p(k_post.cuda_stream)))
             spans_done = torch.cuda.Event()
             spans_done.record(k_post)
         if self.out[slot] is None or self.out[slot][0].numel() < max_runs:

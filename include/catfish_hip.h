@@ -166,6 +166,14 @@ int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets,
 int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_samples, int64_t max_runs,
              int64_t* starts, int64_t* ends, uint64_t* counts, void* stream);
 
+/* cf_postprocess and cf_spans as ONE launch: threshold, correct_short and the run boundaries of the corrected labels (catfish/infer.py:
+ * 128-138, 174-198 and the run-length half of hp_in_pred, :141-162) straight from the probabilities.  Arguments as in the two calls;
+ * labels may be NULL when only the run lists are wanted (then they are never written; min_run > 64 needs the buffer).  counts is zeroed
+ * by the call (on the stream). */
+int cf_postprocess_spans(cf_model* m, const float* probs, const int64_t* read_offsets, const int64_t* read_lengths, int64_t n_reads,
+                         int64_t total_samples, float threshold, int32_t min_run, uint8_t* labels, int64_t max_runs,
+                         int64_t* starts, int64_t* ends, uint64_t* counts, void* stream);
+
 /* Signal ingest on device, replacing normalize_raw_signal + the padding / reshape of
  * infer_class_from_signal (catfish/infer.py:96-105, 31-43) for many reads at once.
  * dac: device int16, the reads' raw DAC samples back to back (after the leader trim of

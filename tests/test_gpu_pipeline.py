@@ -1228,3 +1228,52 @@ def test_file_driven_shard_at_scale_is_invariant_to_batching(tmp_path, model):
                  (table.nonhp_bounds, ref.nonhp_bounds), (table.nonhp_start, ref.nonhp_start), (table.nonhp_end, ref.nonhp_end)):
         assert np.array_equal(a, b)
     assert int(table.has_hp.sum()) > 100                                                   # (the comparison is not vacuous)
+
+
+def test_fused_postprocess_spans_equals_the_two_calls_it_replaces(model):
+    """cf_postprocess_spans (threshold + correct_short + run boundaries in one launch) against cf_postprocess followed
+    by cf_spans on the same probabilities: the same sorted starts / ends and, when asked for, the same labels -- many short reads,
+    runs around min_run, runs touching read ends with ones in the padding behind them, runs across word and 62-word chunk
+    boundaries, a total that is not a multiple of 64; min_run 1, 15, 64 and 65 (the two-kernel fallback); a max_runs too small for
+    the runs found (counts say so, the lists are truncated, the wrapper retries)."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd import batching
+    rng = np.random.default_rng(8)
+    lens = [1, 15, 16, 35, 36, 64, 129, 700, 3967, 3968, 3969, 4096, 9000] + rng.integers(1, 300, size=80).tolist()
+    pk = batching.pack_reads([np.zeros(n) for n in lens])
+    total = pk.n_windows * 35
+    dev = torch.device("cuda", 0)
+    offs, lengths = torch.from_numpy(pk.sample_offsets).to(dev), torch.from_numpy(pk.lengths).to(dev)
+    eng = model.engine
+    for min_run in (15, 1, 64, 65):
+        probs = np.ones(total, dtype=np.float32)
+        for i, n in enumerate(lens):
+            p = np.zeros(n, dtype=np.float32)
+            pos = int(rng.integers(0, 3))
+            while pos < n:
+                run = max(1, int(rng.choice([1, min_run - 1, min_run, min_run + 1, 3 * min_run, int(rng.integers(1, 120))])))
+                p[pos:pos + run] = 0.9
+                pos += run + int(rng.choice([1, 1, 3, 40]))
+            p[p == 0] = 0.1
+            if i % 4 == 0:
+                p[-min(n, min_run + 1):] = 0.9
+            probs[pk.sample_offsets[i]:pk.sample_offsets[i] + n] = p
+        d_probs = torch.from_numpy(probs).to(dev)
+        labels = eng.postprocess_device(d_probs, offs, lengths, min_run=min_run)
+        want_s, want_e = eng.spans_device(labels)
+        got_s, got_e, got_labels = eng.postprocess_spans_device(d_probs, offs, lengths, min_run=min_run, labels=True)
+        assert np.array_equal(got_s, want_s) and np.array_equal(got_e, want_e), min_run
+        assert torch.equal(got_labels, labels) and len(want_s) > 50, min_run
+        only_s, only_e = eng.postprocess_spans_device(d_probs, offs, lengths, min_run=min_run)           # labels never written
+        assert np.array_equal(only_s, want_s) and np.array_equal(only_e, want_e)
+        small_s, small_e = eng.postprocess_spans_device(d_probs, offs, lengths, min_run=min_run, max_runs=7)   # too small: the wrapper retries
+        assert np.array_equal(small_s, want_s) and np.array_equal(small_e, want_e)
+        # and against the per-read reference rules
+        spans = batching.spans_from_runs(got_s, got_e, pk.sample_offsets, pk.n_reads) if hasattr(batching, "spans_from_runs") else None
+        if spans is not None and min_run == 15:
+            for i, n in enumerate(lens):
+                want = oracle.correct_short(oracle.class_from_threshold(probs[pk.sample_offsets[i]:pk.sample_offsets[i] + n]))
+                assert spans[i] == (oracle.hp_in_pred(want) if np.asarray(want).any() else []), i
+    empty_s, empty_e = eng.postprocess_spans_device(torch.zeros(640, device=dev), torch.tensor([0, 640], device=dev),
+                                                    torch.tensor([630], device=dev))
+    assert len(empty_s) == 0 and len(empty_e) == 0
