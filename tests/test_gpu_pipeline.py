@@ -1277,3 +1277,53 @@ def test_fused_postprocess_spans_equals_the_two_calls_it_replaces(model):
     empty_s, empty_e = eng.postprocess_spans_device(torch.zeros(640, device=dev), torch.tensor([0, 640], device=dev),
                                                     torch.tensor([630], device=dev))
     assert len(empty_s) == 0 and len(empty_e) == 0
+
+
+def test_ingest_and_postprocess_kernels_at_scale_random(model):
+    """The round-5 ingest and post-processing kernels on 1500 reads of 1 .. 20 000 samples at once (every register class and the
+    radix path in one launch, reads of all classes next to each other): normalisation bit-exact against numpy per read; corrected labels
+    and run boundaries against the vectorised host rules (``infer.correct_short``, themselves pinned by reference-executed goldens),
+    with smooth random scores (runs of every length) and padding filled with ones."""
+    torch = pytest.importorskip("torch")
+    from catfish_amd import batching, infer
+    rng = np.random.default_rng(23)
+    lens = np.rint(np.exp(rng.uniform(0, np.log(20000), size=1500))).astype(int)
+    reads = []
+    for i, n in enumerate(lens):
+        kind = i % 4
+        if kind == 0:
+            r = np.clip(np.rint(rng.normal(500, 60, size=n)), 0, 2047)
+        elif kind == 1:
+            r = rng.integers(-32768, 32768, size=n)
+        elif kind == 2:
+            r = np.repeat(np.clip(np.rint(rng.normal(450, 80, size=n // 9 + 1)), 0, 2047), 9)[:n]      # dwell-like plateaus: heavy ties
+        else:
+            r = rng.integers(400, 404, size=n)                                                          # four codes only
+        reads.append(r.astype(np.int16))
+    x, win_off = _normalise_on_device(model.engine, reads)
+    for i, r in enumerate(reads):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = infer.normalize_raw_signal(r, "median").astype(np.float32)
+        got = x[win_off[i]:win_off[i + 1]].reshape(-1)
+        assert np.array_equal(got[:len(r)], want, equal_nan=True) and not got[len(r):].any(), (i, len(r))
+    # post-processing over the same packing
+    dev = torch.device("cuda", 0)
+    s_off = win_off * 35
+    total = int(s_off[-1])
+    noise = rng.normal(size=total + 60)
+    smooth = np.convolve(noise, np.ones(31) / 31.0, mode="same")[:total] * 6.0
+    probs = (1.0 / (1.0 + np.exp(-smooth))).astype(np.float32)
+    for i, n in enumerate(lens):
+        probs[s_off[i] + n:s_off[i + 1]] = 1.0                                                          # padding must still come out as 0
+    d_off, d_len = torch.from_numpy(s_off.astype(np.int64)).to(dev), torch.from_numpy(lens.astype(np.int64)).to(dev)
+    starts, ends, labels = model.engine.postprocess_spans_device(torch.from_numpy(probs).to(dev), d_off, d_len, labels=True)
+    labels = labels.cpu().numpy()
+    want_starts, want_ends = [], []
+    for i, n in enumerate(lens):
+        p = probs[s_off[i]:s_off[i] + n]
+        want = np.asarray(infer.correct_short(infer.class_from_threshold(p)))
+        assert np.array_equal(labels[s_off[i]:s_off[i] + n], want) and not labels[s_off[i] + n:s_off[i + 1]].any(), i
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], want, [0]))))
+        want_starts.extend((edges[0::2] + s_off[i]).tolist())
+        want_ends.extend((edges[1::2] + s_off[i]).tolist())
+    assert starts.tolist() == want_starts and ends.tolist() == want_ends and len(want_starts) > 1000
