@@ -190,7 +190,9 @@ def describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, visibl
     cards actually driven, ``n_ranks`` = N, the same on the two end-to-end legs, ``whole_node_end_to_end: null``.  Nothing in a
     rehearsal line is an N-GPU number, and nothing in it can be read as one."""
     from catfish_amd import placement
-    cards = sorted({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks})
+    # a card = (host, PCI address, UUID): two ranks drive the same card only when ALL of it agrees (a runtime that reports one UUID
+    # for every card must not turn a real N-GPU run into a "rehearsal")
+    cards = sorted({(r["host"], r["pci_bus_id"], r["uuid"]) for r in ranks})
     distinct = len(cards)
     result["ranks"] = ranks
     result["collective"] = {"backend": backend, "nccl_init_error": nccl_error, "ranks_seen": ranks_seen,

@@ -679,7 +679,7 @@ def test_bench_line_describes_its_ranks_and_refuses_to_call_a_rehearsal_a_measur
     assert real["collective"] == dict(real["collective"], backend="nccl", nccl_init_error=None, ranks_seen=4, ranks_seen_is_world=True)
     assert "4 GPU(s), one rank each" in real["config"]["parallelism"] and len(real["ranks"]) == 4
 
-    same = bench.describe_ranks(line(4), [rank(r, "uuid0", "%d-%d" % (16 * r, 16 * r + 15)) for r in range(4)], 4, "gloo",
+    same = bench.describe_ranks(line(4), [dict(rank(r, "uuid0", "%d-%d" % (16 * r, 16 * r + 15)), pci_bus_id="0000:0a:00.0") for r in range(4)], 4, "gloo",
                                 "DistBackendError: Duplicate GPU detected", 4, 1)
     assert same["rehearsal"] is True and same["value"] is None and same["rehearsal_value"] == 1.0e9
     assert same["n_gpus"] == 1 and same["n_ranks"] == 4 and same["distinct_devices"] == 1
@@ -691,9 +691,13 @@ def test_bench_line_describes_its_ranks_and_refuses_to_call_a_rehearsal_a_measur
     # two ranks on two hosts with equal uuids are two cards; overlapping CPU sets are reported; a failed parity gate keeps value null
     two = line(2)
     two.update(value=None, unverified_value=7.0)
-    out = bench.describe_ranks(two, [rank(0, "u", "0-7", "a"), rank(1, "u", "4-11", "b")], 2, "gloo", None, 1, 1)
+    out = bench.describe_ranks(two, [dict(rank(0, "u", "0-7", "a"), pci_bus_id="0000:0a:00.0"), dict(rank(1, "u", "4-11", "b"), pci_bus_id="0000:0a:00.0")],
+                               2, "gloo", None, 1, 1)
     assert out["rehearsal"] is False and out["distinct_devices"] == 2 and out["cpu_sets_disjoint"] is False and out["value"] is None
     assert out["collective"]["ranks_seen_is_world"] is False
+    # a runtime that reports the same (or an empty) UUID for every card: the PCI addresses still tell the cards apart
+    blank = bench.describe_ranks(line(4), [rank(r, "", "%d-%d" % (16 * r, 16 * r + 15)) for r in range(4)], 4, "nccl", None, 4, 4)
+    assert blank["rehearsal"] is False and blank["distinct_devices"] == 4 and blank["value"] == 1.0e9
     one = bench.describe_ranks(line(1), [rank(0, "u", "0-63,128-191")], 1, None, None, 1, 1)
     assert one["rehearsal"] is False and one["n_gpus"] == 1 and one["value"] == 1.0e9 and "single process" in one["collective"]["what"]
 
