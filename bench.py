@@ -608,12 +608,18 @@ def main():
     # file pool and the HIP runtime's threads it will start) runs on the CPUs next to its MI355X -- catfish_amd/placement.py.
     # After the CPU baseline, which is entitled to every core of the box.
     from catfish_amd import placement
-    place = placement.bind(launcher_local_rank, local_world,
-                           device_of_rank=(lambda r: shared_device) if shared_device is not None else None)
-
-    progress("bound to CPUs %s (%s); importing torch" % (placement.format_cpulist(place.get("cpus") or []), place.get("source")))
-    import torch
+    import torch                                     # (importing it touches no GPU; nor does counting the devices on this image)
     import torch.distributed as dist
+    n_visible = torch.cuda.device_count()
+    if shared_device is None and 0 < n_visible <= launcher_local_rank:
+        # fewer visible cards than ranks on this node (a launcher that narrows HIP_VISIBLE_DEVICES per rank, or a box with fewer GPUs):
+        # ranks wrap around the cards there are.  Whether that is N cards or a rehearsal is decided from the cards' identities below.
+        local_rank = launcher_local_rank % n_visible
+        sys.stderr.write("bench.py: rank %d: %d visible device(s) for local rank %d -> device %d\n" % (rank, n_visible, launcher_local_rank, local_rank))
+    device_of_rank = (lambda r: shared_device) if shared_device is not None else ((lambda r: r % n_visible) if n_visible > 0 else None)
+    place = placement.bind(launcher_local_rank, local_world, device_of_rank=device_of_rank)
+
+    progress("bound to CPUs %s (%s)" % (placement.format_cpulist(place.get("cpus") or []), place.get("source")))
     # The rank now owns fewer CPUs than the machine has, but OpenMP sized its pool when it was first loaded (numpy, above): a
     # pool of 256 spinning threads on 128 CPUs turned the torch-CPU CHECKER of the config5 leg from 3 s into 266 s (measured,
     # gpurun_out/round5 first run).  One thread per owned CPU at most; the product path runs no torch CPU op at all.
