@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--batches", type=int, default=24)
     ap.add_argument("--reads-per-batch", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight (ReadPipeline.depth)")
     args = ap.parse_args()
     w = bench.load_weights()
     dac = oracle.synthetic_dac(512, 4096, seed=11)
     batches = [[dac[(b * args.reads_per_batch + i) % len(dac)] for i in range(args.reads_per_batch)]
                for b in range(args.batches)]
     eng = HipEngine(w, device=0, max_windows_per_pass=args.reads_per_batch * 118, precision=args.precision)
-    pipe = ReadPipeline(eng, max_samples_per_batch=args.reads_per_batch * 4096)
+    pipe = ReadPipeline(eng, max_samples_per_batch=args.reads_per_batch * 4096, depth=args.depth)
     list(pipe.run(batches[:3]))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
