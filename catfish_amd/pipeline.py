@@ -42,7 +42,8 @@ class ReadPipeline(object):
         # ``depth`` batches may be in flight (staged, launched, not yet collected).  Two is the measured optimum: with three the
         # extra batch's side-stream kernels (normalisation, post-processing) crowd the forward pass of the batch in between
         # (fp32 3.50 -> 3.68 ms per batch, bf16 1.00 -> 1.44 ms, tools/bench_e2e.py); short bf16 batches are better served
-        # by more reads per batch (1024 reads: 1.55 G samples/s host to host)
+        # by more reads per batch (1024 reads: 1.55 G samples/s host to host).  Re-measured in round 5 with the 5x cheaper side kernels
+        # (tools/bench_e2e.py --depth 3): fp32 equal (309.8 vs 310.4 M samples/s), bf16 still 12 % slower (1.26 vs 1.44 G)
         self.depth = max(2, int(depth))
         # where the small kernels run: True = normalisation on the copy stream and post-processing on the download stream, beside
         # the neighbouring batches' forward passes; False = all kernels of a batch in order on the compute stream (only the
