@@ -224,8 +224,10 @@ def current():
 
 
 def bind(local_rank=None, local_world=None, device_of_rank=None, sysfs=None, bdf_of_device=None):
-    """Bind the calling process (all its current threads' future children) to its rank's CPUs.  Call BEFORE the first GPU call
-    and before any pinned allocation.  -> the ``plan`` dict plus ``bound`` (False when ``CATFISH_BIND=0``, when the platform has no
+    """Bind the calling thread -- call it from the main thread at start-up -- and with it every thread started afterwards (they inherit
+    the mask: the loader helper, the library's file pool, the HIP runtime's own) to the rank's CPUs.  Threads that already exist
+    (a BLAS pool created at numpy's import) keep their masks; nothing on the product path runs on them.  Call BEFORE the first GPU
+    call and before any pinned allocation.  -> the ``plan`` dict plus ``bound`` (False when ``CATFISH_BIND=0``, when the platform has no
     ``sched_setaffinity`` or when the call was refused), ``mask_before``, and ``error`` when refused.  Never raises: a job that
     cannot be pinned still runs.  Once per process: a later call returns the first one's record (bench.py binds at start-up and
     then calls ``cli.run_pipeline``, which would otherwise cut its slice of the mask into slices again)."""
