@@ -1,4 +1,4 @@
-"""AddressSanitizer + UBSan build of the host-only C-ABI entry points (the one optional aux item).
+"""AddressSanitizer + UBSan build of the host-only C-ABI entry points, and a ThreadSanitizer run of their thread pools (the one optional aux item).
 
 ``cf_load_npy_int16`` parses file headers nobody vouches for, ``cf_stat_files`` fills a size table from several threads and ``cf_chunks_from_spans`` / ``cf_chunks_json`` write into
 caller-sized buffers (catfish_amd/csrc/loader_host.hpp, chunks_host.hpp: plain host code, no device).  They are compiled here
@@ -37,3 +37,26 @@ def test_host_entry_points_under_asan_and_ubsan(tmp_path):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native", "fuzz_host_entries.py"), lib, str(scratch)],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, env=env, timeout=800)
     assert run.returncode == 0 and run.stdout.strip().endswith("fuzz ok"), run.stdout[-4000:]
+
+
+@pytest.mark.timeout(600)
+def test_host_thread_pools_under_thread_sanitizer(tmp_path):
+    """SURVEY section 5 lists race detection among the aux items: the host entry points that run thread pools (``cf_load_npy_int16``,
+    ``cf_stat_files``, ``cf_listing_sizes``, ``cf_listing_load_npy_int16``) and two independent listings used from two caller threads
+    at once, built with ``g++ -fsanitize=thread`` as a standalone program (tests/native/tsan_driver.cpp: 2 x 240 files, 1 .. 8 pool
+    threads, the error path with several offending files) -- no report, right answers."""
+    if shutil.which("g++") is None or _runtime("libtsan.so") is None:
+        pytest.skip("g++ with the ThreadSanitizer runtime is not installed")
+    exe = str(tmp_path / "tsan_driver")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe,
+                            os.path.join(ROOT, "tests", "native", "tsan_driver.cpp"), "-lpthread"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert build.returncode == 0, build.stdout
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    run = subprocess.run([exe, str(scratch)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=500,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0"))
+    if "FATAL: ThreadSanitizer: unexpected memory mapping" in run.stdout:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert run.returncode == 0 and run.stdout.strip().endswith("tsan ok"), run.stdout[-4000:]
+    assert "ThreadSanitizer" not in run.stdout, run.stdout[-4000:]
