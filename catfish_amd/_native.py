@@ -102,6 +102,7 @@ SYMBOLS = {
     "cf_stat_files": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     "cf_postprocess_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_int32,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cf_crc32c": (C.c_uint32, [C.c_void_p, C.c_int64, C.c_uint32]),
     "cf_listing_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
     "cf_listing_from_names": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "cf_listing_sizes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),

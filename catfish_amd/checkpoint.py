@@ -60,8 +60,28 @@ _CRC_TABLE = _make_crc_table()
 _CRC_TABLE_LIST = [int(v) for v in _CRC_TABLE]
 
 
+_native_crc = None          # cf_crc32c once the library has been found; False when it is not there (this module then stays pure Python)
+
+
 def crc32c(data: bytes, crc: int = 0) -> int:
-    """CRC-32C (Castagnoli), as used by leveldb / TF bundles."""
+    """CRC-32C (Castagnoli), as used by leveldb / TF bundles.  Through the library's ``cf_crc32c`` when it is built (slicing-by-8:
+    the 0.79 MB of inference tensors take 0.4 ms instead of 45), else the byte loop below -- a checksum, the same either way
+    (``crc32c_python`` is the loop, kept callable for the test that compares the two)."""
+    global _native_crc
+    if _native_crc is None:
+        try:
+            from . import _native
+            _native_crc = _native.lib().cf_crc32c
+        except Exception:           # noqa: BLE001 -- no library (a machine that only inspects checkpoints): the Python loop
+            _native_crc = False
+    if _native_crc:
+        buf = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+        return int(_native_crc(buf if isinstance(buf, bytes) else bytes(buf), len(buf), int(crc) & 0xFFFFFFFF))
+    return crc32c_python(data, crc)
+
+
+def crc32c_python(data: bytes, crc: int = 0) -> int:
+    """The same in plain Python (table look-up per byte)."""
     c = crc ^ 0xFFFFFFFF
     tbl = _CRC_TABLE_LIST
     for b in data:

@@ -251,6 +251,10 @@ void cf_listing_close(cf_listing* l);
 int cf_listing_load_npy_int16(const cf_listing* l, int64_t lo, int64_t hi, int16_t* out, int64_t capacity, int64_t* lengths,
                               int64_t* total, int32_t n_threads);
 
+/* CRC-32C (Castagnoli) of n bytes, continuing from crc (0 to start): the checksum of leveldb table blocks and of every tensor in a
+ * TensorFlow checkpoint-V2 bundle, which the checkpoint reader verifies like tf.train.Saver does (catfish/models/rnn_class.py:191-198). */
+uint32_t cf_crc32c(const void* data, int64_t n, uint32_t crc);
+
 /* Training support (BASELINE config 5; the reference's RNN.train_network, catfish/models/rnn_class.py:201-210,
  * differentiates this graph with TensorFlow's autodiff).  One bidirectional GRU layer at a time, fp32 MFMA,
  * on device buffers in the kernels' fragment layout [tile][t][mtile][lane][4] (tile = 16 windows; element

@@ -44,6 +44,8 @@ lib.cf_listing_names.restype = C.c_int
 lib.cf_listing_names.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, P64, P64]
 lib.cf_listing_from_names.restype = C.c_int
 lib.cf_listing_from_names.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+lib.cf_crc32c.restype = C.c_uint32
+lib.cf_crc32c.argtypes = [C.c_char_p, C.c_int64, C.c_uint32]
 lib.cf_listing_load_npy_int16.restype = C.c_int
 lib.cf_listing_load_npy_int16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P16, C.c_int64, P64, P64, C.c_int32]
 lib.cf_listing_close.restype = None
@@ -403,6 +405,15 @@ def fuzz_listing(names, data):
         shutil.rmtree(box, ignore_errors=True)
 
 
+@settings(max_examples=max(20, int(os.environ.get("FUZZ_EXAMPLES", 250)) // 2), **SETTINGS)
+@given(st.binary(min_size=0, max_size=600), st.integers(0, 2 ** 32 - 1), st.integers(0, 9))
+def fuzz_crc(data, seed, skip):
+    """cf_crc32c on exactly-sized buffers at every alignment (reads past the end are a sanitizer report) against the byte loop."""
+    from catfish_amd.checkpoint import crc32c_python
+    piece = data[min(skip, len(data)):]
+    assert lib.cf_crc32c(piece, len(piece), seed) == crc32c_python(piece, seed)
+
+
 def bad_arguments():
     """NULL tables, negative sizes, descending bounds: an error code, never a fault."""
     z = arr64([0, 0])
@@ -428,6 +439,7 @@ def bad_arguments():
     assert lib.cf_listing_open(os.fsencode(os.path.join(SCRATCH, "no such directory")), C.byref(h), None, None) == CF_ERR_INVALID and not h.value
     assert lib.cf_listing_sizes(None, 0, 0, None, 1) == CF_ERR_INVALID and lib.cf_listing_names(None, 0, 0, None, 0, None, None) == CF_ERR_INVALID
     lib.cf_listing_close(None)
+    assert lib.cf_crc32c(None, 0, 5) == 5 and lib.cf_crc32c(None, 10, 7) == 7 and lib.cf_crc32c(b"123456789", 9, 0) == 0xE3069283
 
 
 if __name__ == "__main__":
@@ -437,4 +449,5 @@ if __name__ == "__main__":
     fuzz_stat()
     fuzz_listing()
     fuzz_listing_loader()
+    fuzz_crc()
     print("fuzz ok")

@@ -111,3 +111,20 @@ def test_writer_reproduces_the_reference_bundle_byte_for_byte(tmp_path):
     # fingerprints of the reference's files (so a reader of this test sees what was compared)
     assert hashlib.sha256(open(out + ".index", "rb").read()).hexdigest().startswith("471de3f2a6280c50")
     assert hashlib.sha256(open(out + ".data-00000-of-00001", "rb").read()).hexdigest().startswith("8d3af93055b35b16")
+
+
+def test_native_crc32c_equals_the_python_loop():
+    """checkpoint.crc32c goes through the library's cf_crc32c (slicing-by-8) when it is built: same values as the byte loop on every
+    length and alignment class, with and without a running CRC, and the standard check value of CRC-32C."""
+    from catfish_amd import checkpoint as c
+    rng = np.random.default_rng(0)
+    assert c.crc32c(b"123456789") == c.crc32c_python(b"123456789") == 0xE3069283
+    blob = rng.integers(0, 256, size=5000, dtype=np.uint8).tobytes()
+    for n in (0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1000, 4999):
+        for off in (0, 1, 3, 7):
+            piece = blob[off:off + n]
+            assert c.crc32c(piece) == c.crc32c_python(piece), (n, off)
+            assert c.crc32c(piece, 0xDEADBEEF) == c.crc32c_python(piece, 0xDEADBEEF), (n, off)
+    first, rest = blob[:1234], blob[1234:]
+    assert c.crc32c(rest, c.crc32c(first)) == c.crc32c(blob)                # continuing a CRC equals one pass over the whole
+    assert c.crc32c(bytearray(blob)) == c.crc32c(memoryview(blob)) == c.crc32c(blob)
