@@ -575,6 +575,8 @@ def main():
                     help="skip the informational legs (other precisions, config 4, host-to-host pipeline)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the informational sharded_gather leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reads-per-rank", type=int, default=SHARDED_READS_PER_RANK,
+                    help="reads (files) per rank of the sharded_gather / cli_end_to_end legs (BASELINE configs[2]: 12 500 = 100 000 on 8)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="run untimed steps for this long before the W warm-up steps: the GPU clocks down while the CPU "
                          "baseline leg (or process start-up) keeps it idle, and a short W would time the clock ramp")
@@ -583,6 +585,7 @@ def main():
                     help="run ONE informational leg in its profiling form and print its JSON (the command tools/collect_traffic_config4.sh "
                          "puts under rocprofv3); no headline line")
     args = ap.parse_args()
+    globals()["SHARDED_READS_PER_RANK"] = int(args.reads_per_rank)
     if args.only_leg == "config4":
         import torch
         torch.cuda.set_device(0)
