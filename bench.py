@@ -183,7 +183,7 @@ def nearer_roof(roof, precision, samples, seconds):
     return roof
 
 
-def describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, visible_devices):
+def describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, visible_devices, rccl_probe=None):
     """Who ran what where, into the line (pure bookkeeping, tested on the CPU): ``ranks`` (every rank's record), ``collective``,
     ``distinct_devices``, ``cpu_sets_disjoint``, and -- when ranks SHARED a card (``CATFISH_BENCH_DEVICE``, or fewer GPUs than
     ranks) -- the rehearsal marking: ``rehearsal: true``, ``value: null`` (the number moves to ``rehearsal_value``), ``n_gpus`` = the
@@ -196,9 +196,11 @@ def describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, visibl
     distinct = len(cards)
     result["ranks"] = ranks
     result["collective"] = {"backend": backend, "nccl_init_error": nccl_error, "ranks_seen": ranks_seen,
-                            "ranks_seen_is_world": bool(ranks_seen == world),
-                            "what": "timing barrier + MAX over ranks only (no collective on the data path); ranks_seen = all_reduce(sum) of 1 "
-                                    "per rank over that backend" if world > 1 else "single process: no process group"}
+                            "ranks_seen_is_world": bool(ranks_seen == world), "rccl_probe": rccl_probe,
+                            "what": "timing barrier + MAX over ranks on the host group (gloo), whatever RCCL does: the data path has no "
+                                    "collective, so the clock does not depend on one; ranks_seen = all_reduce(sum) of 1 per rank over that "
+                                    "group; rccl_probe = one all-reduce of a device scalar over a second, RCCL group with a short timeout "
+                                    "(did this node's RCCL see all ranks?)" if world > 1 else "single process: no process group"}
     result["distinct_devices"] = distinct
     result["visible_devices_rank0"] = visible_devices
     cpu_sets = [set(placement.parse_cpulist(r["cpus"])) for r in ranks]
@@ -226,6 +228,47 @@ def describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, visibl
         result["rehearsal_whole_node_end_to_end"] = result["whole_node_end_to_end"]
         result["whole_node_end_to_end"] = None
     return result
+
+
+RCCL_PROBE_TIMEOUT_S = 90.0
+
+
+def probe_rccl(dist, torch, local_rank, timeout_s=None):
+    """Bring RCCL ("nccl" on ROCm) up over a SECOND process group and all-reduce one device scalar: -> dict(ok, ranks_seen, seconds,
+    error, timeout_s).  Bounded: the group is created with ``timeout_s`` and waits block (TORCH_NCCL_BLOCKING_WAIT), so a collective
+    that does not complete raises here instead of hanging the run or being torn down by the watchdog; any failure is recorded and
+    the group dropped.  The default (gloo) group must exist already; nothing the benchmark times uses the probed group."""
+    import datetime
+    timeout_s = float(os.environ.get("CATFISH_RCCL_PROBE_TIMEOUT_S", RCCL_PROBE_TIMEOUT_S)) if timeout_s is None else float(timeout_s)
+    out = {"ok": False, "ranks_seen": None, "seconds": None, "error": None, "timeout_s": timeout_s}
+    if os.environ.get("CATFISH_RCCL_PROBE", "1") == "0":
+        out["error"] = "skipped (CATFISH_RCCL_PROBE=0)"
+        return out
+    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+    t0 = time.perf_counter()
+    group = None
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        one = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(one, group=group)
+        torch.cuda.synchronize()
+        out["ranks_seen"] = int(round(float(one.item())))
+        out["ok"] = out["ranks_seen"] == dist.get_world_size()
+    except Exception as exc:      # pragma: no cover - depends on the node
+        out["error"] = "%s: %s" % (type(exc).__name__, " ".join(str(exc).split())[:400])
+        sys.stderr.write("bench.py: RCCL probe failed (%s); the timing barrier is on gloo either way\n" % out["error"])
+    out["seconds"] = time.perf_counter() - t0
+    # every rank learns whether ALL ranks got through (a probe that worked on some ranks only is not a working RCCL) -- over gloo
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, bool(out["ok"]))
+    if not all(flags) and out["ok"]:
+        out["ok"], out["error"] = False, "the probe failed on rank(s) %s" % [r for r, f in enumerate(flags) if not f]
+    if group is not None:
+        try:
+            dist.destroy_process_group(group)
+        except Exception as exc:      # pragma: no cover
+            out["destroy_error"] = "%s: %s" % (type(exc).__name__, " ".join(str(exc).split())[:200])
+    return out
 
 
 def timed_steps(eng, batches, outs, n, torch):
@@ -480,7 +523,7 @@ def leg_sharded_gather(eng, weights, rank, world, dist, torch):
 
 def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
     """The product entry point on BASELINE configs[2]'s shape, files -> JSON: ``catfish_amd.cli.run_pipeline`` (the body of
-    catfish/catfish:23-94 up to the split step) over a directory of 12 500 x 4096-sample int16 reads per rank.  Every rank
+    catfish/catfish:23-94, split step included but timed apart) over a directory of 12 500 x 4096-sample int16 reads per rank.  Every rank
     loads, classifies AND merges / centres / complements its own files (catfish/catfish:50-82), formats its part of the two
     JSON documents and writes it at its offset.  Timed: everything but the network load -- output directories, the listing of the
     input directory (catfish/catfish:49-50; it grows with the job), classification, merge tail, documents on disk; page cache
@@ -522,8 +565,9 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
             failure = exc
         total = time.perf_counter() - t0
         per_rank = [None] * world
-        mine = {k: timings.get(k) for k in ("listing_s", "model_s", "infer_s", "chunks_s", "write_s")}
-        mine.update(rank=rank, total_s=total, failed=None if failure is None else "%s: %s" % (type(failure).__name__, failure))
+        mine = {k: timings.get(k) for k in ("listing_s", "model_s", "infer_s", "chunks_s", "write_s", "split_s")}
+        mine.update(rank=rank, total_s=total, failed=None if failure is None else "%s: %s" % (type(failure).__name__, failure),
+                    split=res.get("split") if failure is None else None)
         if world > 1:
             dist.all_gather_object(per_rank, mine, group=host_group)      # doubles as the barrier every rank reaches
         else:
@@ -534,8 +578,9 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
         if rank != 0:
             return None
         # the network load is set-up; the directory listing (names on every rank, sizes of a rank's block, the agreement) is part
-        # of the job -- it grows with the number of files -- and is counted
-        dt = total - timings["model_s"]
+        # of the job -- it grows with the number of files -- and is counted.  The split step (every rank writes the int16 slices of its
+        # reads) is file writing after the documents: timed apart (``split_s``), reported beside ``value``, not inside it
+        dt = total - timings["model_s"] - timings["split_s"]
         post = timings.get("write_s", 0.0)
         with open(os.path.join(root, "out", "TEMP", "hp_positions.json")) as fh:
             hp = json.load(fh)
@@ -543,12 +588,38 @@ def leg_cli_end_to_end(weights, rank, world, local_rank, dist, torch):
             nonhp = json.load(fh)
         ok = (res["reads"] == n_total == len(nonhp) and res["samples"] == n_total * READ_LEN
               and len(hp) == res["reads_with_hp"] and sum(len(v) for v in hp.values()) == res["hp_chunks"])
+        # untimed CONTENT check (catfish/catfish:55-82, 85-92): the documents' entries and the split files of the first, a middle and
+        # the last file of rank 0's block against the oracle's classification + the per-read Python rules + numpy slicing
+        from oracle import catfish_oracle as oracle
+        lo, hi = res["file_range"]
+        checked = []
+        for k in sorted({lo, (lo + hi) // 2, hi - 1}) if hi > lo else []:
+            name = res["files"][k - lo]
+            dac = squiggle_dac(np.random.default_rng([1, int(name[len("read_"):-len(".npy")])]), READ_LEN)
+            spans, length, _ = oracle.infer_read(oracle.normalize_raw_signal(dac), weights, np.float32)
+            merged, non = cli.chunks_of_read([list(sp) for sp in spans], length, 1000)
+            same = hp.get(name) == merged and nonhp.get(name) == json.loads(json.dumps(non))
+            for j, (s0, s1) in enumerate((merged or []) + (non if merged else [])):
+                part = os.path.join(root, "out", "TEMP", "HP" if j < len(merged) else "nonHP", "%s_%d.npy" % (name.split(".")[0], j))
+                same = same and os.path.exists(part) and np.array_equal(np.load(part), dac[s0:s1])
+            checked.append({"file": name, "hp_chunks": 0 if merged is None else len(merged), "matches_oracle": bool(same)})
+            ok = ok and same
+        ok = ok and len(checked) > 0
+        split_counts = [p.get("split") for p in per_rank]
         return {"workload": "configs[2] through the CLI: %d files x %d samples (seed 1) over %d rank(s), %d per rank; chunk_size "
                             "1000" % (n_total, READ_LEN, world, SHARDED_READS_PER_RANK),
-                "value": n_total * READ_LEN / dt, "unit": "samples/s", "seconds": dt, "model_load_seconds_excluded": timings["model_s"],
-                "listing_s": timings["listing_s"],
+                "value": n_total * READ_LEN / dt if ok else None, "unit": "samples/s", "seconds": dt,
+                "model_load_seconds_excluded": timings["model_s"], "listing_s": timings["listing_s"],
+                "split_s": max(p["split_s"] for p in per_rank), "split_seconds_excluded": timings["split_s"],
+                "split": {"files_hp": sum(c["files_hp"] for c in split_counts), "files_nonhp": sum(c["files_nonhp"] for c in split_counts),
+                          "reads": sum(c["reads"] for c in split_counts), "samples": sum(c["samples"] for c in split_counts),
+                          "what": "catfish/split_f5.py:8-81 for int16 .npy reads: signal[s0:s1] of every chunk as HP/<stem>_<k>.npy or "
+                                  "nonHP/<stem>_<k>.npy, every rank its own reads; slowest rank's seconds; beside value, not inside it "
+                                  "(the reference writes gzip-9 HDF5 copies here -- not a comparison)"},
+                "content_checked": checked,
                 "timed_region": "output directories + listing of the input directory (every rank: names; its block: sizes; the ranks' "
-                                "agreement) + classification + merge tail + documents on disk; only the network load is left out",
+                                "agreement) + classification + merge tail + documents on disk; the network load and the split step "
+                                "(split_s) are left out",
                 "rank0": {"listing_s": timings.get("listing_s"), "infer_s": timings.get("infer_s"), "chunks_s": timings.get("chunks_s"),
                           "write_s": timings.get("write_s")},
                 "per_rank": per_rank,
@@ -632,26 +703,19 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    backend, nccl_error, ranks_seen = None, None, 1
+    backend, nccl_error, ranks_seen, rccl_probe = None, None, 1, None
     if world > 1:
-        # The data path has no collective; the process group only serves the timing barrier and the MAX over
-        # ranks.  RCCL ("nccl") first; if it cannot initialise on this node, fall back to gloo (host barrier) -- and SAY so in
-        # the line (``collective``): a scaling record must show which library carried the barrier and how many ranks it saw.
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            probe = torch.ones(1, device=torch.device("cuda", local_rank))
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
-            backend, ranks_seen = "nccl", int(round(float(probe.item())))
-        except Exception as exc:      # pragma: no cover - depends on the node
-            nccl_error = "%s: %s" % (type(exc).__name__, " ".join(str(exc).split())[:400])
-            sys.stderr.write("bench.py: nccl init failed (%s); using gloo for the timing barrier\n" % exc)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            dist.init_process_group("gloo")
-            probe = torch.ones(1)
-            dist.all_reduce(probe)
-            backend, ranks_seen = "gloo", int(round(float(probe.item())))
+        # The data path has no collective, so the clock does not depend on RCCL either: the process group that carries the timing
+        # barrier and the MAX over ranks is the HOST group (gloo), always.  RCCL is brought up beside it as a PROBE -- one all-reduce
+        # of a device scalar over a second group with a short timeout -- so that the line shows whether the node's RCCL saw all N
+        # ranks, and a stuck or failing bring-up costs at most RCCL_PROBE_TIMEOUT_S and a note (``collective.rccl_probe``), never the run.
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("CATFISH_DIST_TIMEOUT_S", "1800"))))
+        probe = torch.ones(1)
+        dist.all_reduce(probe)
+        backend, ranks_seen = "gloo", int(round(float(probe.item())))
+        rccl_probe = probe_rccl(dist, torch, local_rank)
+        nccl_error = rccl_probe.get("error")
 
     progress("process group %s; creating the engine on device %d" % (backend, local_rank))
     from catfish_amd.engine import HipEngine
@@ -681,9 +745,8 @@ def main():
         eng.infer_device(batches[i % n_batches], out=outs[i & 1])
     torch.cuda.synchronize()
 
-    if not args.no_kernel_events:
-        eng.profile_enable(True, every=4)        # HIP events around every kernel of every 4th step of the timed region
-        eng.profile_reset()
+    # the K timed steps: no instrumentation inside the clock (per-kernel HIP events are collected in a pass of their own below)
+    eng.profile_enable(False)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -692,13 +755,21 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    kern = eng.profile_read() if not args.no_kernel_events else {}
-    eng.profile_enable(False)
     eng.check_error()
+    # ... then an equally long UNTIMED pass over the same batches with HIP events around every kernel of every step (on the
+    # streams the kernels are launched on): ``kernels_ms`` and ``roofline.avg_launch_ms`` come from this pass, ``value`` from the one above
+    kern, dt_events = {}, None
+    if not args.no_kernel_events:
+        eng.profile_enable(True, every=1)
+        eng.profile_reset()
+        dt_events = timed_steps(eng, batches, outs, args.steps, torch)
+        kern = eng.profile_read()
+        eng.profile_enable(False)
+        eng.check_error()
 
     dt_local = dt
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64)          # host group (gloo): the clock does not depend on RCCL
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -746,6 +817,10 @@ def main():
             "whole_pass": {"achieved_tflops": value / world * FLOP_PER_SAMPLE / 1e12,
                            "frac_of_mfma_peak": value / world * FLOP_PER_SAMPLE / 1e12 / peak},
             "kernels_ms": {k: v[0] / v[1] for k, v in kern.items()},
+            "kernel_events": {"pass": "separate untimed pass of %d steps over the same batches right after the timed steps, HIP events "
+                                      "around every kernel of every step; the timed steps run with events off" % args.steps,
+                              "ms_per_step_with_events": None if dt_events is None else dt_events / args.steps * 1e3,
+                              "launches_timed": {k: v[1] for k, v in kern.items()}},
             "parity": {"max_abs_dp_vs_fp64_oracle": max_dp, "label_match_vs_fp32_oracle": match,
                        "label_match_after_correct_short": match_corrected, "gate": gate,
                        "min_label_match": min_match, "passed": parity_ok,
@@ -847,7 +922,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, torch.cuda.device_count())
+        describe_ranks(result, ranks, world, backend, nccl_error, ranks_seen, torch.cuda.device_count(), rccl_probe)
         print(json.dumps(result))
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY GATE FAILED (max |dp| %.3g, label match %.5f): no value reported\n" % (max_dp, match))

@@ -7,8 +7,9 @@ All reads of the directory go through packed multi-read launches instead of one 
 the per-file loop with its merge tail (catfish/catfish:50-82) shards over the GPUs of the node: ``--gpus N`` (an MI355X
 addition) or ``python -m torch.distributed.run --nproc-per-node N -m catfish_amd.cli ...``.
 
-The FAST5 splitter (catfish/split_f5.py) is disk I/O around h5py and out of scope: when h5py
-is not installed the chunk coordinates are written as JSON next to the would-be split files.
+The chunk coordinates are written as two JSON documents under ``<split-dir>/TEMP`` and the reads are cut there into
+``HP/<stem>_<k>.npy`` / ``nonHP/<stem>_<k>.npy`` (``catfish_amd/split.py``: the reference's split_f5.split_signal for int16
+``.npy`` / ``.npz`` / ``.bin`` reads; its HDF5 container is outside this path).
 """
 from __future__ import annotations
 
@@ -74,8 +75,8 @@ def chunks_of_read(hp_positions, len_read, chunk_size=1000):
 
 
 def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN", network_type="ResNetRNN",
-                 checkpoint=30000, device=None, precision="fp32", timings=None, gather_table=False, bind=True):
-    """Body of the reference's ``main`` (catfish/catfish:23-94) up to the split step.
+                 checkpoint=30000, device=None, precision="fp32", timings=None, gather_table=False, bind=False):
+    """Body of the reference's ``main`` (catfish/catfish:23-94), split step included.
 
     Under ``torch.distributed.run`` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the per-file loop of
     catfish/catfish:50-82 is sharded WITH its tail, and so is the writing: every rank reads and classifies its own block of
@@ -87,23 +88,25 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
 
     Returns on every rank the totals ``dict(reads, samples, reads_with_hp, hp_chunks, bytes)`` plus ``files`` / ``file_range``: the
     names of the files THIS rank classified and their index range in the agreed order of the directory (the whole list is never
-    built as Python strings: ``sharding.DirListing``).  With ``gather_table=True`` rank 0's dict also holds ``table``, the
+    built as Python strings: ``sharding.DirListing``) and ``split``, this rank's counts of the split step (``split.split_reads``).
+    With ``gather_table=True`` rank 0's dict also holds ``table``, the
     ``chunks.ChunkTable`` over all files gathered from the ranks, and its ``files`` are all names
     (``table.to_dicts(files)`` = the reference's ``hp_dict`` / ``nonhp_dict``).  ``timings`` (optional dict) receives
     this rank's ``listing_s`` (output directories, the directory listing and the ranks' agreement on it), ``model_s`` (network
-    load up to the ranks' agreement on it), ``setup_s`` (their sum), ``infer_s``, ``chunks_s``, ``write_s`` and ``placement``
-    (the CPUs the rank bound itself to, ``placement.summary``).  ``bind``: bind this PROCESS to the CPUs next to the rank's GPU before
-    the first GPU call (``catfish_amd/placement.py``; process-wide and permanent, like a ``taskset`` around the job -- pass False when
-    the caller manages affinity itself).
+    load up to the ranks' agreement on it), ``setup_s`` (their sum), ``infer_s``, ``chunks_s``, ``write_s``, ``split_s`` and ``placement``
+    (the CPUs the rank is bound to, ``placement.summary``).  ``bind=True``: bind this PROCESS to the CPUs next to the rank's GPU before
+    the first GPU call (``catfish_amd/placement.py``; process-wide and permanent, like a ``taskset`` around the job).  The command line
+    (``main``) does that; a library caller keeps its affinity unless it asks (the default), and a binding the process took earlier
+    (``placement.bind`` at start-up, as bench.py does) is reported as it is.
     """
     import time
-    from . import chunks, placement, sharding
+    from . import chunks, placement, sharding, split
     rank, world, local_rank = sharding.dist_env()
     # before the first GPU call and the first pinned allocation: this rank, its loader thread and the library's file pool run
-    # on the CPUs next to its MI355X (a no-op when the caller -- bench.py -- bound the process already)
-    # (``bind=False``, or CATFISH_BIND=0, for a caller that manages its process's affinity itself: the binding is process-wide and stays)
+    # on the CPUs next to its MI355X (a no-op when the caller -- bench.py -- bound the process already; CATFISH_BIND=0 turns it off)
     place = placement.bind(local_rank, device_of_rank=(lambda r: _pick_device(r) if (device is None or r != local_rank) else device)) \
-        if bind else {"bound": False, "source": "off (bind=False)", "cpus": sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []}
+        if bind else (placement.current() or {"bound": False, "source": "off (bind=False)",
+                                              "cpus": sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []})
     own_group = sharding.init_host_group()
     timings = {} if timings is None else timings
     timings["placement"] = placement.summary(place)
@@ -168,9 +171,20 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         result = chunks.write_json_documents(temp_dir, table, my_files, group=host_group)
         timings["write_s"] = time.perf_counter() - t3
         result["files"], result["file_range"] = my_files, ((mine[0], mine[-1] + 1) if mine else (0, 0))
+        # 3. the split (catfish/catfish:85-92 -> split_f5.split_signal): every rank cuts the reads IT classified, after the documents
+        # are agreed on; no gather.  Timed apart (``split_s``): it is file writing, not part of the classification rate.
+        t4 = time.perf_counter()
+        split_error, split_counts = None, None
+        try:
+            my_paths = ["{}/{}".format(input_dir, name) for name in my_files]
+            split_counts = split.split_reads(table, my_paths, "{}/HP".format(temp_dir), "{}/nonHP".format(temp_dir))
+        except Exception as exc:                          # noqa: BLE001 -- one rank's full disk fails the job on every rank
+            split_error = exc
+        sharding.agree_or_raise(split_error, "splitting the reads", group=host_group)
+        timings["split_s"] = time.perf_counter() - t4
+        result["split"] = split_counts                    # THIS rank's counts: reads cut, files_hp, files_nonhp, samples
         if rank == 0:
-            print("Chunk coordinates written to {} (FAST5 splitting needs h5py and is outside this path) in {}".format(
-                temp_dir, datetime.timedelta(seconds=timings["write_s"])))
+            print("Finished splitting the raw signals in {}".format(datetime.timedelta(seconds=timings["split_s"])))
         if gather_table:
             import torch.distributed as dist
             if world > 1:
@@ -239,7 +253,7 @@ def _build_click_main():
             argv = ["-i", input_dir, "-s", split_dir, "-c", str(chunk_size), "--network-path", network_path,
                     "--precision", precision]
             sys.exit(launch_ranks(gpus, argv))
-        run_pipeline(input_dir, split_dir, chunk_size, network_path=network_path, precision=precision)
+        run_pipeline(input_dir, split_dir, chunk_size, network_path=network_path, precision=precision, bind=True)
 
     return main
 

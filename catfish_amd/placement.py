@@ -277,12 +277,18 @@ def verify(placement, actual_bdf, local_rank=None, local_world=None, device_of_r
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if local_world is None:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    source, cpus = locality_cpus(actual, placement.get("mask_before") or sorted(os.sched_getaffinity(0)), sysfs)
+    allowed = placement.get("mask_before") or sorted(os.sched_getaffinity(0))
+    source, cpus = locality_cpus(actual, allowed, sysfs)
     if source == "none":
         return placement                                           # nothing better known: the split stays
-    # the other ranks' real devices are unknown here (no exchange): assume the node's usual layout -- ranks sharing this locality set are
-    # the ones whose planned set equals it; without that knowledge take the slice by local rank over the local world
-    new = slice_for(local_rank, local_world, cpus, sysfs) if len(cpus) // max(1, local_world) >= MIN_CPUS_PER_RANK else cpus
+    # the other ranks' real devices are unknown here (no exchange): take their PLANNED devices, as ``plan`` does -- the ranks sharing this
+    # locality set are this rank plus those whose planned set equals it, and the set is cut among them (4 of 8 ranks per socket: a quarter
+    # of the socket each, not an eighth)
+    device_of_rank = (lambda r: r) if device_of_rank is None else device_of_rank
+    peers = [r for r in range(max(1, int(local_world)))
+             if r == local_rank or tuple(locality_cpus(device_bdf(device_of_rank(r), sysfs), allowed, sysfs)[1]) == tuple(cpus)]
+    new = slice_for(peers.index(local_rank), len(peers), cpus, sysfs)
+    placement["shared_with"] = peers
     try:
         os.sched_setaffinity(0, new)
         placement.update(cpus=sorted(new), source=source, bdf=actual, rebound_after_gpu_init=True)

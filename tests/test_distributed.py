@@ -347,6 +347,13 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
         def no_space(fd, data, offset):
             raise OSError(errno.ENOSPC, "No space left on device")
         chunks._pwrite_all = no_space
+    if break_setup == "split" and rank == world - 1:                      # ... or when it writes its chunk files
+        import errno
+        from catfish_amd import split
+
+        def no_space_for_chunks(dest_name, signal, s0, s1):
+            raise OSError(errno.ENOSPC, "No space left on device", dest_name)
+        split._write_chunk = no_space_for_chunks
     if break_setup == "short":                                             # every pwrite stops after 7 bytes
         real_pwrite = os.pwrite
         os.pwrite = lambda fd, data, offset: real_pwrite(fd, bytes(data[:7]), offset)
@@ -406,6 +413,20 @@ def test_eight_ranks_write_the_same_bytes_as_one(tmp_path):
         spans, length = infer_read(np.load(tmp_path / "reads" / name))
         merged, non = cli.chunks_of_read([list(s) for s in spans], length, 300)
         assert hp.get(name) == merged and nonhp[name] == json.loads(json.dumps(non))
+    # the split step (catfish/catfish:85-92 -> split_f5.py:8-81): every rank cut ITS reads -- same file set and same bytes as one
+    # rank, each file numpy's save of signal[s0:s1], the index running on from the HP chunks into the non-HP ones
+    import io
+    expected = {}
+    for name in hp:
+        signal = np.load(tmp_path / "reads" / name)
+        for k, (s0, s1) in enumerate(hp[name] + nonhp[name]):
+            buf = io.BytesIO()
+            np.save(buf, signal[s0:s1])
+            expected["%s/%s_%d.npy" % ("HP" if k < len(hp[name]) else "nonHP", name.split(".")[0], k)] = buf.getvalue()
+    for out in ("out8", "out1"):
+        got = {"%s/%s" % (d, f): (tmp_path / out / "TEMP" / d / f).read_bytes()
+               for d in ("HP", "nonHP") for f in os.listdir(tmp_path / out / "TEMP" / d)}
+        assert got == expected and len(got) > len(hp)
 
 
 @pytest.mark.timeout(120)
@@ -446,6 +467,20 @@ def test_a_rank_whose_write_fails_fails_the_job_at_once(tmp_path):
     assert r1[1].startswith("OSError") and "No space left" in r1[1]
     assert r0[1].startswith("RuntimeError") and "writing the chunk documents failed on rank 1: OSError" in r0[1]
     assert sorted(os.listdir(tmp_path / "out" / "TEMP")) == ["HP", "nonHP"]         # nothing half-written, no .part left
+
+
+@pytest.mark.timeout(120)
+def test_a_rank_whose_split_fails_fails_the_job_at_once(tmp_path):
+    """The split step is per rank and ends in an agreement: one rank's full disk raises on every rank within seconds (an exception
+    aborts the run, split_f5.py:23-32); the documents, agreed on before, stay."""
+    import torch.multiprocessing as mp
+    _write_reads(str(tmp_path / "reads"), 6)
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), 6, "out", "split"), nprocs=2, join=True)
+    r0, r1 = ((tmp_path / ("out.rank%d" % r)).read_text().split(" ", 1) for r in (0, 1))
+    assert float(r0[0]) < 30 and float(r1[0]) < 30
+    assert r1[1].startswith("OSError") and "No space left" in r1[1]
+    assert r0[1].startswith("RuntimeError") and "splitting the reads failed on rank 1: OSError" in r0[1]
+    assert (tmp_path / "out" / "TEMP" / "hp_positions.json").exists()
 
 
 @pytest.mark.timeout(120)

@@ -606,3 +606,40 @@ def test_torch_operator_resnetrnn_forward(ckpt_weights, golden_read):
         torch.ops.catfish.resnetrnn_forward(x.reshape(-1, 59), packed)                                  # windows are 35 samples
     ops.clear_engine_cache()
     assert not ops._ENGINES
+
+
+def test_torch_operator_runs_the_weights_it_is_given_after_address_reuse(ckpt_weights):
+    """pack A, run, delete, pack B of the same geometry into the memory A had (forced: ``empty_like`` + ``copy_``
+    right after the free) -> B's probabilities, bit-identical to ``HipEngine(B)``; the old (address, version, numel) key returned A's."""
+    import gc
+    import torch
+    import catfish_amd.torch_ops as ops
+    from catfish_amd.engine import HipEngine
+    ops.clear_engine_cache()
+    wb = {k: np.array(v) for k, v in ckpt_weights.items()}
+    wb["final_fully_connected/bias"] = wb["final_fully_connected/bias"] + np.float32(1.5)              # every probability moves
+    x = torch.randn(64, 35, device="cuda")
+    outs = {}
+    for tag, w in (("a", ckpt_weights), ("b", wb)):
+        e = HipEngine(w, device=0)
+        outs[tag] = e.infer_device(x).clone()
+        e.close()
+    assert not torch.equal(outs["a"], outs["b"])
+    template = ops.pack_weights(wb)
+    same_address = 0
+    for _ in range(5):
+        a = ops.pack_weights(ckpt_weights)
+        addr = a.untyped_storage().data_ptr()
+        assert torch.equal(torch.ops.catfish.resnetrnn_forward(x, a), outs["a"])
+        del a
+        gc.collect()
+        b = torch.empty_like(template)
+        b.copy_(template)                                                                              # version 1, maybe A's address
+        same_address += b.untyped_storage().data_ptr() == addr
+        assert torch.equal(torch.ops.catfish.resnetrnn_forward(x, b), outs["b"])
+        b2 = ops.pack_weights(wb)                                                                      # version 0, like A had
+        assert torch.equal(torch.ops.catfish.resnetrnn_forward(x, b2), outs["b"])
+        del b, b2
+        gc.collect()
+    assert len(ops._ENGINES) == 2
+    ops.clear_engine_cache()

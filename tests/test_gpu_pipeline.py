@@ -874,6 +874,19 @@ def test_cli_end_to_end(tmp_path, ckpt_weights, monkeypatch):
             assert nonhp[name] == cli.nonhp_complement(merged, length)
         else:
             assert name not in hp
+    # the split step (catfish/catfish:85-92 -> split_f5.py:8-81): signal[s0:s1] of every chunk as an int16 .npy, HP chunks first,
+    # the index running on into the non-HP ones; reads without homopolymers are not split
+    want = {}
+    for name in hp:
+        for k, (s0, s1) in enumerate(hp[name] + nonhp[name]):
+            want["%s/%s_%d.npy" % ("HP" if k < len(hp[name]) else "nonHP", name.split(".")[0], k)] = dacs[name][s0:s1]
+    assert hp and want
+    got = {"%s/%s" % (d, f) for d in ("HP", "nonHP") for f in os.listdir(tmp_path / "out" / "TEMP" / d)}
+    assert got == set(want)
+    for rel, samples in want.items():
+        back = np.load(tmp_path / "out" / "TEMP" / rel)
+        assert back.dtype == np.int16 and np.array_equal(back, samples)
+    assert "Finished splitting the raw signals in" in res.output
     # second run into the same directory fails like the reference (os.makedirs on an existing TEMP/HP)
     res2 = CliRunner().invoke(cli._build_click_main(), ["-i", str(reads), "-s", str(tmp_path / "out")])
     assert res2.exit_code != 0

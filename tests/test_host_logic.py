@@ -736,6 +736,55 @@ def test_torch_operator_is_registered_and_has_no_cpu_path():
     assert g2["n_layers_res"] == 0 and sorted(b2) == sorted(ops.tensor_names(2, 0)) and b2[ops.tensor_names(2, 0)[0]].shape == (1 + 64, 128)
 
 
+def test_torch_operator_keys_its_engines_on_the_weights_content(monkeypatch):
+    """the engine cache was keyed on (storage address, version, numel, device); the allocator hands a freed packed
+    tensor's address to the next one of the same size, so a second checkpoint of the same geometry silently ran with the first
+    one's engine.  The key is a digest of the packed bytes now: pack A, use, delete, pack B into the SAME memory -> B's engine; equal
+    content under another address -> the same engine; an in-place change of a live tensor -> a new engine."""
+    import gc
+    import torch
+    import catfish_amd.engine as engine_mod
+    import catfish_amd.torch_ops as ops
+    from oracle import catfish_oracle as oracle
+    built = []
+
+    class FakeEngine(object):
+        def __init__(self, weights, device=0, **geom):
+            self.mark = float(weights["final_fully_connected/bias"][0])
+            built.append(self.mark)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(engine_mod, "HipEngine", FakeEngine)
+    ops.clear_engine_cache()
+    wa, wb = oracle.random_weights(seed=11), oracle.random_weights(seed=12)
+    wa["final_fully_connected/bias"] = np.array([0.25], np.float32)
+    wb["final_fully_connected/bias"] = np.array([0.75], np.float32)
+    reused = 0
+    for _ in range(10):
+        a = ops.pack_weights(wa)
+        addr = a.untyped_storage().data_ptr()
+        assert ops._engine_for(a, 0).mark == 0.25 and ops._engine_for(a, 0).mark == 0.25
+        del a
+        gc.collect()
+        b = ops.pack_weights(wb)                                      # same size, version 0, very likely the same address
+        reused += b.untyped_storage().data_ptr() == addr
+        assert ops._engine_for(b, 0).mark == 0.75
+        del b
+        gc.collect()
+    assert built == [0.25, 0.75]                                     # one engine per CONTENT, however often it was re-packed
+    a = ops.pack_weights(wa)
+    twin = a.clone()
+    assert ops._engine_for(twin, 0) is ops._engine_for(a, 0)          # another address, equal bytes
+    assert ops._engine_for(a, 1) is not ops._engine_for(a, 0)         # another device: its own engine
+    a[-1] = 0.5                                                      # in place on a live tensor: torch's version counter moves
+    assert ops._engine_for(a, 0).mark == 0.5 and ops._engine_for(twin, 0).mark == 0.25
+    assert not ops._SEEN or all(ref() is not None for ref, _v, _k in ops._SEEN.values())      # dead tensors left the identity table
+    ops.clear_engine_cache()
+    assert not ops._ENGINES and not ops._SEEN
+
+
 def test_file_batches_ramp_up_and_cover_every_read_once():
     """sharding._batches_by_samples: consecutive batches under the sample cap; with ``ramp`` the first batches are capped lower (the
     device starts sooner on a shard that begins with reading files) and every read still appears exactly once, in order."""
