@@ -840,6 +840,22 @@ __global__ __launch_bounds__(256) void spans_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// Kernel 4c: a read packed without padding (read_lengths[r] == read_offsets[r + 1] - read_offsets[r]) touches the next one, and
+// spans_kernel, which sees labels only, reports a positive run across the boundary as one.  One thread per read boundary splits it.
+__global__ __launch_bounds__(256) void spans_cut_kernel(const uint8_t* __restrict__ labels, const int64_t* __restrict__ read_offsets,
+                                                        const int64_t* __restrict__ read_lengths, int64_t n_reads, int64_t total, int64_t max_runs,
+                                                        int64_t* __restrict__ starts, int64_t* __restrict__ ends,
+                                                        unsigned long long* __restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x + 1;         // boundary between read r - 1 and read r
+    if (r >= n_reads) return;
+    const int64_t at = read_offsets[r];
+    if (at <= 0 || at >= total || read_offsets[r - 1] + read_lengths[r - 1] != at || read_lengths[r] <= 0) return;
+    if (!labels[at - 1] || !labels[at]) return;
+    const unsigned long long ks = atomicAdd(&counts[0], 1ull), ke = atomicAdd(&counts[1], 1ull);
+    if ((int64_t)ks < max_runs) starts[ks] = at;
+    if ((int64_t)ke < max_runs) ends[ke] = at;
+}
+
 // ------------------------------------------------------------------------------------------
 // Kernel 5: signal ingest -- per-read median / MAD normalisation of raw int16 DAC samples
 // (normalize_raw_signal, infer.py:96-105) fused with the zero padding + window packing of
@@ -1821,11 +1837,25 @@ extern "C" int cf_postprocess_spans(cf_model* m, const float* probs, const int64
         return fail(CF_ERR_INVALID, "cf_postprocess_spans: null buffer");
     const bool v1 = cf_knob("CATFISH_INGEST_V1") && atoi(cf_knob("CATFISH_INGEST_V1")) != 0;
     if (v1 || min_run > 64 || (reinterpret_cast<uintptr_t>(labels) & 15u) != 0) {
-        // what the bit-mask kernel does not cover goes through the two calls it replaces (they need a labels buffer)
-        if (!labels) return fail(CF_ERR_INVALID, "cf_postprocess_spans: min_run > 64 needs a labels buffer");
-        const int rc = cf_postprocess(m, probs, read_offsets, read_lengths, n_reads, total_samples, threshold, min_run, labels, stream);
-        if (rc != CF_OK) return rc;
-        return cf_spans(m, labels, total_samples, max_runs, starts, ends, counts, stream);
+        // what the bit-mask kernel does not cover (min_run > 64, an unaligned labels pointer) or is told not to take (the
+        // CATFISH_INGEST_V1 A/B knob) goes through the two calls it replaces.  They need a labels buffer: a caller that asked for the
+        // spans only (labels NULL -- the streaming pipeline) gets a stream-ordered temporary one.
+        uint8_t* lab = labels;
+        if (!lab) {
+            hipError_t e = hipMallocAsync((void**)&lab, (size_t)total_samples, s);
+            if (e != hipSuccess) return fail(CF_ERR_NOMEM, std::string("cf_postprocess_spans: no device memory for the temporary labels: ") + hipGetErrorString(e));
+        }
+        int rc = cf_postprocess(m, probs, read_offsets, read_lengths, n_reads, total_samples, threshold, min_run, lab, stream);
+        if (rc == CF_OK) rc = cf_spans(m, lab, total_samples, max_runs, starts, ends, counts, stream);
+        if (rc == CF_OK && n_reads > 1) {
+            // cf_spans sees labels only: where an UNPADDED read's last sample and the next read's first are both positive it found one
+            // run; cut it at the read boundary (one end + one start more; the lists are sorted before pairing, so order is free)
+            hipLaunchKernelGGL(spans_cut_kernel, dim3((unsigned)((n_reads - 1 + 255) / 256)), dim3(256), 0, s, lab, read_offsets, read_lengths,
+                               n_reads, total_samples, max_runs, starts, ends, reinterpret_cast<unsigned long long*>(counts));
+            if (hipGetLastError() != hipSuccess) rc = fail(CF_ERR_HIP, "cf_postprocess_spans: launch failed");
+        }
+        if (!labels) (void)hipFreeAsync(lab, s);
+        return rc;
     }
     size_t pi = 0;
     int rc = prof_begin(m, SLOT_POST, s, &pi);

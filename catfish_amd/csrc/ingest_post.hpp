@@ -171,7 +171,7 @@ __device__ __forceinline__ cf_w192 w192_shl(const cf_w192& x, int s) {     // to
 }
 
 // SPANS: the run boundaries of the corrected labels leave with the same launch (cf_postprocess_spans: the "one kernel returning
-// spans" of SURVEY.md 8f-1) -- a run starts where a bit is set and its lower neighbour is not, m & ~(m << 1), and ends likewise;
+// spans" of SURVEY.md 8f-1) -- a run starts where a bit is set and its lower neighbour is not (or a read begins), and ends likewise;
 // the neighbours across the word's edges are the final bits 63 / 0 of the window's outer words, which are exact (see above: what is
 // incomplete there never comes within min_run - 1 bits of the middle word).  A wave reserves room for all its boundaries with one
 // global atomic per list (prefix sums of the lanes' popcounts), like spans_kernel; labels may then be NULL (not written at all).
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void postprocess_bits_kernel(const float* __re
     const int64_t w = w0 - 1 + lane;                                       // this lane's word
     const int64_t base = w * 64;
     // 1. which samples of my word are real samples of a read
-    unsigned long long valid = 0;
+    unsigned long long valid = 0, first = 0;                               // first: bits where a read begins (runs are cut there)
     if (w >= 0 && base < total) {
         int64_t lo = 0, hi = n_reads;                                      // largest r with read_offsets[r] <= base
         while (hi - lo > 1) {
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void postprocess_bits_kernel(const float* __re
             const int64_t end = beg + read_lengths[r];
             const int64_t a = beg > base ? beg - base : 0, b = (end < base + 64 ? end : base + 64) - base;
             if (b > a) valid |= (b - a >= 64 ? ~0ull : ((1ull << (b - a)) - 1ull)) << a;
+            if (beg >= base) first |= 1ull << (beg - base);
         }
     }
     // 2. threshold bits: word j of the wave's window lands in lane j
@@ -221,9 +222,16 @@ __global__ __launch_bounds__(256) void postprocess_bits_kernel(const float* __re
     x.n = (unsigned long long)__shfl_down((long long)mine, 1);
     if (lane == 0) x.p = 0;
     if (lane == 63) x.n = 0;
-    int have = 1;                                                          // x marks positions where `have` ones begin
+    // A run lies inside the real part of ITS read (postprocess_kernel's contract).  Padding bits are 0 and separate the reads, but a
+    // read packed WITHOUT padding touches the next one: the ones of `have` samples beginning at i join those beginning at i + have
+    // only when no read begins at i + have.  (The last, overlapping step below needs no such mask: its two stretches share samples.)
+    cf_w192 cut;
+    cut.m = ~first;
+    cut.p = ~(unsigned long long)__shfl_up((long long)first, 1);
+    cut.n = ~(unsigned long long)__shfl_down((long long)first, 1);
+    int have = 1;                                                          // x marks positions where `have` ones of one read begin
     while (2 * have <= min_run) {
-        const cf_w192 s = w192_shr(x, have);
+        const cf_w192 s = w192_shr({x.p & cut.p, x.m & cut.m, x.n & cut.n}, have);
         x = {x.p & s.p, x.m & s.m, x.n & s.n};
         have *= 2;
     }
@@ -245,8 +253,9 @@ __global__ __launch_bounds__(256) void postprocess_bits_kernel(const float* __re
     if constexpr (SPANS) {
         unsigned long long sm = 0, em = 0;
         if (payload) {
-            sm = x.m & ~((x.m << 1) | (x.p >> 63));
-            em = x.m & ~((x.m >> 1) | (x.n << 63));
+            // ... or where a read begins (an unpadded read's last run and the next read's first are two runs, not one)
+            sm = x.m & (~((x.m << 1) | (x.p >> 63)) | ~cut.m);
+            em = x.m & (~((x.m >> 1) | (x.n << 63)) | ((~cut.m >> 1) | (~cut.n << 63)));
         }
         const unsigned cs = (unsigned)__popcll(sm), ce = (unsigned)__popcll(em);
         unsigned ps = cs, pe = ce;                                         // inclusive prefix sums over the wave

@@ -176,7 +176,7 @@ class HipEngine(object):
         if max_runs is None:
             max_runs = total // max(1, int(min_run)) + 16
         dev = probs.device
-        lab = torch.empty(total, dtype=torch.uint8, device=dev) if (labels or int(min_run) > 64) else None
+        lab = torch.empty(total, dtype=torch.uint8, device=dev) if labels else None      # NULL: the library never writes labels
         starts = torch.empty(max_runs, dtype=torch.int64, device=dev)
         ends = torch.empty(max_runs, dtype=torch.int64, device=dev)
         counts = torch.empty(2, dtype=torch.int64, device=dev)

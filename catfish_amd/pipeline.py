@@ -153,15 +153,18 @@ class ReadPipeline(object):
             total = C.c_int64(0)
             rc = lib.cf_listing_load_npy_int16(handle, int(lo), int(hi), C.c_void_p(stage.data_ptr()), cap,
                                                lengths.ctypes.data_as(C.c_void_p), C.byref(total), threads)
-            return rc, lengths, int(total.value)
+            # the library's error text is per THREAD: read it here, where the call ran (the main thread would see a stale or empty one)
+            msg = lib.cf_last_error().decode("utf-8", "replace") if rc != N.CF_OK else ""
+            return rc, lengths, int(total.value), msg
         return (slot, self._loader.submit(work))
 
     def launch_preloaded(self, pre):
         """Launch the batch ``preload_listing`` read.  None when it needs the general loader (nothing has been consumed)."""
         slot, fut = pre
-        rc, lengths, total = fut.result()
+        rc, lengths, total, msg = fut.result()
         if rc == N.CF_ERR_NOMEM:
-            N.check(rc)
+            raise N.CatfishHipError(rc, msg)
+        self.last_preload_note = msg if rc != N.CF_OK else ""    # why the batch goes to the general loader (names the offending file)
         if rc != N.CF_OK or len(lengths) == 0:
             return None
         if slot != self.k % self.depth or self.inflight[slot] is not None:

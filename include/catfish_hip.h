@@ -159,7 +159,10 @@ int cf_postprocess(cf_model* m, const float* probs, const int64_t* read_offsets,
 
 /* Run boundaries of the corrected labels on device (the run-length half of hp_in_pred,
  * catfish/infer.py:141-162).  labels: device uint8[total_samples] as written by cf_postprocess
- * (padding = 0, so runs never cross reads).  starts / ends: device int64[max_runs], receive the packed
+ * (padding = 0, so runs never cross reads -- this call sees labels only: where a read is packed WITHOUT padding,
+ * read_lengths[r] == read_offsets[r+1] - read_offsets[r], and its last sample and the next read's first are both positive,
+ * they come out as one run; catfish/infer.py:31-36 pads every read by at least one sample, and cf_postprocess_spans, which
+ * has the read table, cuts such runs at the boundary).  starts / ends: device int64[max_runs], receive the packed
  * positions of every run's first sample and one-past-last sample in arbitrary order (sort both
  * ascending: the k-th start pairs with the k-th end); counts: device uint64[2] = number of starts and
  * of ends found (may exceed max_runs, in which case the lists are truncated). */
@@ -168,8 +171,9 @@ int cf_spans(cf_model* m, const uint8_t* labels, int64_t total_samples, int64_t 
 
 /* cf_postprocess and cf_spans as ONE launch: threshold, correct_short and the run boundaries of the corrected labels (catfish/infer.py:
  * 128-138, 174-198 and the run-length half of hp_in_pred, :141-162) straight from the probabilities.  Arguments as in the two calls;
- * labels may be NULL when only the run lists are wanted (then they are never written; min_run > 64 needs the buffer).  counts is zeroed
- * by the call (on the stream). */
+ * labels may be NULL when only the run lists are wanted (then they are never written).  A run lies inside the real part of ITS read,
+ * also when reads are packed without padding: adjacent positive runs of two such reads are two runs.  counts is zeroed by the call (on
+ * the stream). */
 int cf_postprocess_spans(cf_model* m, const float* probs, const int64_t* read_offsets, const int64_t* read_lengths, int64_t n_reads,
                          int64_t total_samples, float threshold, int32_t min_run, uint8_t* labels, int64_t max_runs,
                          int64_t* starts, int64_t* ends, uint64_t* counts, void* stream);

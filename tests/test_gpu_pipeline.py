@@ -1153,6 +1153,54 @@ def test_bitmask_postprocess_kernel_matches_oracle_and_round_1_kernel(model, mon
         assert got[:real].tolist() == ([1] * real if real >= 15 else [0] * real) and not got[real:].any(), n
 
 
+def test_postprocess_keeps_runs_inside_their_read_when_reads_are_packed_without_padding(model, monkeypatch):
+    """the bit-mask kernel eroded across one flat validity mask, so with a read table WITHOUT padding
+    (read_lengths[r] == read_offsets[r + 1] - read_offsets[r]: legal through the C ABI, never produced by the framework's packers) a
+    7-run ending read r and an 8-run starting read r + 1 survived correct_short as one 15-run, and the spans variant emitted one span
+    across the boundary.  Runs are cut where a read begins now: labels equal the per-read oracle (infer.py:174-198) and round 1's
+    per-sample kernel bit for bit, spans equal the per-read runs, on both code paths, with boundaries at every position of a word."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(8)
+    lens = [7, 8, 64, 1, 14, 15, 16, 63, 65, 100, 30, 30, 128, 5, 9, 4000, 33] + rng.integers(1, 90, size=80).tolist()
+    offs_h = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offs_h[-1])
+    dev = torch.device("cuda", 0)
+    offs, lengths = torch.from_numpy(offs_h).to(dev), torch.from_numpy(np.asarray(lens, np.int64)).to(dev)
+    for min_run in (15, 2, 33, 64, 65):
+        per_read = []
+        for i, n in enumerate(lens):
+            p = (rng.random(n) < 0.35).astype(np.float32)
+            if i % 2 == 0:
+                p[-min(n, max(1, min_run // 2)):] = 1.0                    # a short run ending with the read ...
+            else:
+                p[:min(n, min_run - min_run // 2)] = 1.0                   # ... meets one starting the next: min_run together
+            if i % 5 == 0:
+                p[:] = 1.0                                                 # whole reads positive: long runs on both sides of a boundary
+            per_read.append(p)
+        probs = torch.from_numpy(np.concatenate(per_read)).to(dev)
+        want = np.concatenate([np.asarray(oracle.correct_short(oracle.class_from_threshold(p), min_run), dtype=np.uint8) for p in per_read])
+        want_runs = []
+        for i, p in enumerate(per_read):
+            lab = np.concatenate([[0], np.asarray(oracle.correct_short(oracle.class_from_threshold(p), min_run)), [0]])
+            edges = np.flatnonzero(np.diff(lab))
+            want_runs += [(int(offs_h[i] + a), int(offs_h[i] + b)) for a, b in zip(edges[0::2], edges[1::2])]
+        assert any(a == o for a, _b in want_runs for o in offs_h[1:-1]) and any(b == o for _a, b in want_runs for o in offs_h[1:-1])
+        for v1 in (False, True):
+            if v1:
+                monkeypatch.setenv("CATFISH_DEBUG_KNOBS", "1")
+                monkeypatch.setenv("CATFISH_INGEST_V1", "1")
+            else:
+                monkeypatch.delenv("CATFISH_INGEST_V1", raising=False)
+            got = model.engine.postprocess_device(probs, offs, lengths, min_run=min_run).cpu().numpy()
+            assert np.array_equal(got, want), (min_run, v1)
+            for with_labels in (True, False):                              # labels NULL: also on the fallback path (ADVICE r05, low)
+                res = model.engine.postprocess_spans_device(probs, offs, lengths, min_run=min_run, labels=with_labels)
+                assert list(zip(res[0].tolist(), res[1].tolist())) == want_runs, (min_run, v1, with_labels)
+                if with_labels:
+                    assert np.array_equal(res[2].cpu().numpy(), want), (min_run, v1)
+    monkeypatch.delenv("CATFISH_INGEST_V1", raising=False)
+
+
 def test_cli_directory_of_mixed_formats_and_many_batches(tmp_path, ckpt_weights):
     """`cli.run_pipeline` over a directory the native listing path cannot take whole: int16 ``.npy`` vectors (the fast path: listing
     ranges, files preloaded by the helper thread), an ``.npz`` (key ``raw``), a headerless ``.bin``, an ``.npy`` holding int32 codes

@@ -18,12 +18,62 @@ from catfish_amd.training import Trainer  # noqa: E402
 import bench  # noqa: E402
 
 
+def profile_only(B, steps):
+    """One trainer, ``steps`` steps, and where a step's wall time goes: the host copies of the batch (``load_batch``: numpy -> static
+    device buffers), the graph launch, the device time of the replayed graph (HIP events on the stream it runs on) and the
+    loss read-back that ends the step.  Prints one JSON line."""
+    w = bench.load_weights()
+    pool = bench.make_reads(max(8, B // 100 + 1), seed=5).reshape(-1, 35)
+    rng = np.random.default_rng(0)
+    x = pool[rng.permutation(len(pool))[:B]]
+    y = np.repeat((np.arange(B) % 2)[:, None], 35, axis=1).astype(np.float32)
+    tr = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=0.8, device="cuda", seed=0)
+    for _ in range(5):
+        tr.train_step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(x, y)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    # the same step taken apart (untimed above): host copies, launch, device, read-back
+    sx, b, sloss = tr._static
+    parts = {"load_batch_ms": 0.0, "replay_call_ms": 0.0, "graph_device_ms": 0.0, "loss_readback_ms": 0.0}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(steps):
+        t = time.perf_counter()
+        tr.step_impl.load_batch(b, x, y)
+        torch.cuda.synchronize()
+        parts["load_batch_ms"] += time.perf_counter() - t
+        t = time.perf_counter()
+        e0.record()
+        tr._graph.replay()
+        e1.record()
+        parts["replay_call_ms"] += time.perf_counter() - t
+        t = time.perf_counter()
+        float(sloss.detach())
+        parts["loss_readback_ms"] += time.perf_counter() - t
+        parts["graph_device_ms"] += e0.elapsed_time(e1) * 1e-3
+    print(json.dumps({"batch": B, "steps": steps, "ms_per_step": wall * 1e3, "windows_per_s": B / wall,
+                      "parts_ms": {k: v / steps * 1e3 for k, v in parts.items()},
+                      "what": "parts measured in a second loop with a synchronise after the batch copies: load_batch = numpy -> static device "
+                              "buffers (pageable H2D), replay_call = host time of hipGraphLaunch, graph_device = HIP events around the "
+                              "replay on its stream, loss_readback = the D2H of the loss that ends a step (waits for the graph)"}))
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256, help="windows per training batch (the reference trains with 256)")
+    ap.add_argument("--profile-only", action="store_true",
+                    help="only the default (native, graph-replayed) trainer: warm-up, then --steps timed steps with a host/device "
+                         "breakdown -- the command to put under rocprofv3 --kernel-trace --stats (every traced launch then belongs "
+                         "to a whole step: kernel-time sum / steps against wall per step = the launch-gap share)")
+    ap.add_argument("--steps", type=int, default=30)
     args = ap.parse_args()
     B = args.batch
+    if args.profile_only:
+        return profile_only(B, args.steps)
     w = bench.load_weights()
     reads = bench.make_reads(max(8, B // 100 + 1), seed=5).reshape(-1, 35)
     rng = np.random.default_rng(0)

@@ -1,0 +1,42 @@
+#!/bin/bash
+# GPU box: the round-6 measurements the docs cite, written under gpurun_out/round6/ (copy what is judged into profiles/).
+# usage:  bash tools/collect_round6.sh <commit> [stage ...]
+#   stages: tests bench train rehearse6 prof streams   (default: tests bench train)
+COMMIT=${1:-unknown}; shift
+STAGES=${@:-tests bench train}
+ROOT="$GRAFT_REPO_ROOT"
+OUT="$ROOT/gpurun_out/round6"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+echo "commit $COMMIT stages $STAGES" > $OUT/commit.txt
+for S in $STAGES; do
+  case $S in
+    tests) timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1 || { echo "gpu tests FAILED" >> $OUT/commit.txt; tail -40 $OUT/gpu_tests.log; exit 1; } ;;
+    bench) timeout -k 10 700 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo "bench FAILED" >> $OUT/commit.txt; tail -20 $OUT/bench_default.err; exit 1; } ;;
+    train)   # config 5 (the training step): host/device breakdown of a step + rocprofv3 kernel trace of the same command, at 256 and 4096 windows
+      for B in 256 4096; do
+        timeout -k 10 300 python3 tools/bench_train.py --batch $B --profile-only --steps 200 > $OUT/train_parts_$B.json 2> $OUT/train_parts_$B.err \
+          || { echo "train parts $B FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_parts_$B.err; exit 1; }
+        rm -rf /tmp/kt_train_$B
+        timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_train_$B -o kt -- python3 tools/bench_train.py --batch $B --profile-only --steps 200 \
+          > $OUT/train_prof_$B.json 2> $OUT/train_prof_$B.err || { echo "train prof $B FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_prof_$B.err; exit 1; }
+        cp $(find /tmp/kt_train_$B -name "*kernel_stats.csv" | head -1) $OUT/train_kernel_stats_$B.csv
+        python3 tools/train_gap.py $OUT/train_kernel_stats_$B.csv $OUT/train_prof_$B.json $OUT/train_parts_$B.json > $OUT/train_gap_$B.json
+      done ;;
+    rehearse6)   # the N > 1 launch path at configs[2]'s per-rank size, SIX ranks on ONE card (the box allows at most 6 processes on its GPU): a rehearsal (value null), never a measurement
+      CATFISH_BENCH_DEVICE=0 CATFISH_DEVICE=0 CATFISH_RCCL_PROBE_TIMEOUT_S=60 timeout -k 10 1000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 6 \
+        --master-addr 127.0.0.1 --master-port 29506 bench.py --gpus 6 --steps 20 --warmup 5 --reads-per-rank 12500 \
+        > $OUT/bench_6ranks_one_gpu.json 2> $OUT/bench_6ranks.err || { echo "rehearsal FAILED" >> $OUT/commit.txt; tail -30 $OUT/bench_6ranks.err; exit 1; } ;;
+    prof)
+      for P in fp32; do
+        rm -rf /tmp/kt_$P
+        rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$P -o kt -- python3 bench.py --precision $P --no-cpu-baseline --no-extra-precisions --no-sharded-leg > $OUT/bench_prof_$P.json 2>/dev/null
+        cp $(find /tmp/kt_$P -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_$P.csv
+      done ;;
+    streams)   # two engines on two streams, alternate steps, configs[1] -- the gated look at the fp32 tail
+      timeout -k 10 300 python3 tools/exp_two_engines.py > $OUT/two_engines_overlap.json 2> $OUT/two_engines_overlap.err \
+        || { echo "streams FAILED" >> $OUT/commit.txt; tail -20 $OUT/two_engines_overlap.err; exit 1; } ;;
+  esac
+  echo "$S done" >> $OUT/commit.txt
+done
+echo "all done" >> $OUT/commit.txt
