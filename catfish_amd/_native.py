@@ -32,12 +32,13 @@ def _lib_path():
 
 
 LIB_PATH = DEFAULT_LIB_PATH
-CF_ABI_VERSION = 5            # include/catfish_hip.h
+CF_ABI_VERSION = 6            # include/catfish_hip.h
 
 CF_OK = 0
 CF_ERR_INVALID = -1
 CF_ERR_HIP = -2
 CF_ERR_NOMEM = -3
+CF_ERR_IO = -4
 CF_WINDOW = 35
 CF_PROF_SLOTS = 12
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
@@ -109,6 +110,8 @@ SYMBOLS = {
     "cf_listing_names": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "cf_listing_close": (None, [C.c_void_p]),
     "cf_listing_load_npy_int16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cf_listing_split_npy_int16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p]),
     "cf_chunks_json": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64]),
     "cf_gru_pack_map": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -202,6 +205,8 @@ def check(rc):
         msg = lib().cf_last_error().decode("utf-8", "replace")
         if rc == CF_ERR_INVALID:
             raise ValueError("catfish_hip: " + msg)
+        if rc == CF_ERR_IO:
+            raise OSError("catfish_hip: " + msg)
         raise CatfishHipError(rc, msg)
 
 

@@ -177,7 +177,8 @@ def run_pipeline(input_dir, split_dir, chunk_size=1000, network_path="ResNetRNN"
         split_error, split_counts = None, None
         try:
             my_paths = ["{}/{}".format(input_dir, name) for name in my_files]
-            split_counts = split.split_reads(table, my_paths, "{}/HP".format(temp_dir), "{}/nonHP".format(temp_dir))
+            split_counts = split.split_reads(table, my_paths, "{}/HP".format(temp_dir), "{}/nonHP".format(temp_dir),
+                                             listing=listing, lo=mine[0] if mine else 0)
         except Exception as exc:                          # noqa: BLE001 -- one rank's full disk fails the job on every rank
             split_error = exc
         sharding.agree_or_raise(split_error, "splitting the reads", group=host_group)

@@ -2386,6 +2386,7 @@ extern "C" int64_t cf_workspace_bytes(const cf_model* m) { return m ? m->ws_byte
 extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
 #include "chunks_host.hpp"
 #include "loader_host.hpp"
+#include "split_host.hpp"
 
 // Which card is HIP device `device` of this process (rank placement and the N > 1 bench line: catfish_amd/placement.py)
 extern "C" int cf_device_identity(int device, char* pci_bus_id, int64_t bus_cap, char* uuid_hex, int64_t uuid_cap) {

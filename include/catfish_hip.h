@@ -33,12 +33,13 @@ extern "C" {
 #define CF_ERR_INVALID -1     /* bad argument / unsupported geometry (Python raises ValueError) */
 #define CF_ERR_HIP -2         /* a HIP runtime call failed */
 #define CF_ERR_NOMEM -3
+#define CF_ERR_IO -4          /* a file could not be opened / written (Python raises OSError); host entry points only */
 
 #define CF_WINDOW 35          /* rnn_class.py:27 (self.window) */
 
 /* Bumped whenever a signature or a struct of this header changes; cf_abi_version() returns the value the library was built
  * with, so a binding can refuse a stale libcatfish_hip.so instead of calling it with the wrong arguments. */
-#define CF_ABI_VERSION 5
+#define CF_ABI_VERSION 6
 
 /* Arithmetic of the biGRU layers (the residual blocks, the hidden state, the gates'
  * sigmoid/tanh and all accumulation are fp32 in every mode). */
@@ -254,6 +255,20 @@ void cf_listing_close(cf_listing* l);
  * built by the caller.  Every entry must be named *.npy; same results, errors and buffers as cf_load_npy_int16. */
 int cf_listing_load_npy_int16(const cf_listing* l, int64_t lo, int64_t hi, int16_t* out, int64_t capacity, int64_t* lengths,
                               int64_t* total, int32_t n_threads);
+
+/* The split step, catfish/catfish:85-92 -> split_f5.split_signal (catfish/split_f5.py:8-81), for entries [lo, hi) of a listing that are
+ * one-dimensional little-endian int16 .npy reads.  Row r of the two CSR chunk tables (cf_chunks_from_spans' outputs; bounds[hi - lo + 1])
+ * belongs to entry lo + r.  Every read WITH homopolymer rows (`for read in hp_dict`, catfish/catfish:88) is read once and cut:
+ * signal[start:end] (Python slice rules: a bound below zero counts from the end, both are clamped to the read) of its HP rows goes to
+ * <hp_dir>/<stem>_<k>.npy, of its non-HP rows to <nonhp_dir>/<stem>_<k>.npy -- <stem> = the entry's name up to its FIRST dot
+ * (split_f5.py:39,65), k = 0, 1, ... over the HP rows and on into the non-HP rows (:34,57,81) -- each file byte for byte numpy.save of that
+ * int16 slice.  (The reference writes a gzip-9 HDF5 copy of the input per piece; HDF5 is outside this path.)  Reads sharing a stem overwrite
+ * each other's pieces in listing order, as in the reference.  n_threads host threads (<= 0: 4).  counts (may be NULL): int64[4] = reads cut,
+ * HP files, non-HP files, samples written.  CF_ERR_INVALID names the first entry that is not such a read (nothing is rolled back: pieces are
+ * rewritten whole by whoever repeats the step); CF_ERR_IO names the first file that could not be written, with the system's reason. */
+int cf_listing_split_npy_int16(const cf_listing* l, int64_t lo, int64_t hi, const int64_t* hp_bounds, const int64_t* hp_start,
+                               const int64_t* hp_end, const int64_t* nonhp_bounds, const int64_t* nonhp_start, const int64_t* nonhp_end,
+                               const char* hp_dir, const char* nonhp_dir, int32_t n_threads, int64_t* counts);
 
 /* CRC-32C (Castagnoli) of n bytes, continuing from crc (0 to start): the checksum of leveldb table blocks and of every tensor in a
  * TensorFlow checkpoint-V2 bundle, which the checkpoint reader verifies like tf.train.Saver does (catfish/models/rnn_class.py:191-198). */

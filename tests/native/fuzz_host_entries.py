@@ -10,6 +10,8 @@ child process with the sanitizer runtime preloaded; not collected by pytest itse
   capacities.  Judge: the per-read Python rules (catfish_amd.cli.chunks_of_read) and json.dumps.
 * cf_stat_files (loader_host.hpp) writes one size per name from several threads: files, empty files, directories, missing entries,
   zero to 700 names.  Judge: os.stat.
+* cf_listing_split_npy_int16 (split_host.hpp) slices reads at coordinates nobody vouches for (below zero, beyond the read, end before
+  start) and writes files: random reads, chunk rows and thread counts; names with several dots or none.  Judge: numpy slicing + numpy.save.
 * cf_listing_open / _sizes / _names / _close (loader_host.hpp): random name sets against sorted(), blocks into exactly-sized buffers.
 A sanitizer report aborts the process (non-zero exit); a wrong answer raises.
 """
@@ -48,9 +50,11 @@ lib.cf_crc32c.restype = C.c_uint32
 lib.cf_crc32c.argtypes = [C.c_char_p, C.c_int64, C.c_uint32]
 lib.cf_listing_load_npy_int16.restype = C.c_int
 lib.cf_listing_load_npy_int16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P16, C.c_int64, P64, P64, C.c_int32]
+lib.cf_listing_split_npy_int16.restype = C.c_int
+lib.cf_listing_split_npy_int16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P64, P64, P64, P64, P64, P64, C.c_char_p, C.c_char_p, C.c_int32, P64]
 lib.cf_listing_close.restype = None
 lib.cf_listing_close.argtypes = [C.c_void_p]
-CF_OK, CF_ERR_INVALID = 0, -1
+CF_OK, CF_ERR_INVALID, CF_ERR_IO = 0, -1, -4
 SETTINGS = dict(deadline=None, database=None, suppress_health_check=list(HealthCheck))
 
 
@@ -220,6 +224,78 @@ def fuzz_listing_loader(cases, room, n_threads):
                 assert total.value == total_want and list(lengths)[:len(names)] == [len(w) for w in want]
                 if total_want:
                     assert np.array_equal(np.ctypeslib.as_array(out)[:total_want], np.concatenate(want))
+        finally:
+            lib.cf_listing_close(handle)
+    finally:
+        shutil.rmtree(box, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ cf_listing_split_npy_int16
+@st.composite
+def split_case(draw):
+    n_reads = draw(st.integers(1, 7))
+    stems = draw(st.lists(st.sampled_from(["r1", "r2", "ch3.read9", "x", "x.y", "", "r10"]), min_size=n_reads, max_size=n_reads, unique=True))
+    reads = []
+    for stem in stems:
+        n = draw(st.integers(0, 400))
+        kind = draw(st.sampled_from(["good", "good", "good", "good", "int32"]))
+        coord = st.integers(-n - 30, n + 30)
+        hp = draw(st.lists(st.tuples(coord, coord), min_size=0, max_size=4))
+        non = draw(st.lists(st.tuples(coord, coord), min_size=0, max_size=4))
+        reads.append((stem + ".npy", n, kind, hp, non))
+    return reads
+
+
+@settings(max_examples=int(os.environ.get("FUZZ_EXAMPLES", 250)), **SETTINGS)
+@given(split_case(), st.integers(1, 8), st.integers(0, 2 ** 31))
+def fuzz_split(reads, n_threads, seed):
+    """Every read with HP rows cut at its rows, k running on from the HP rows into the non-HP rows; reads without HP rows untouched; a
+    read that is not an int16 vector among those to cut -> CF_ERR_INVALID; same-stem reads (x.npy, x.y.npy) overwrite in listing order."""
+    import shutil
+    import tempfile
+    box = tempfile.mkdtemp(dir=SCRATCH)
+    try:
+        rng = np.random.default_rng(seed)
+        for d in ("in", "HP", "nonHP"):
+            os.makedirs(os.path.join(box, d))
+        reads = sorted(reads, key=lambda r: os.fsencode(r[0]))
+        signals = {}
+        for name, n, kind, _hp, _non in reads:
+            sig = rng.integers(-32768, 32768, size=n).astype(np.int16)
+            signals[name] = sig
+            with open(os.path.join(box, "in", name), "wb") as fh:
+                fh.write(npy_bytes(sig if kind == "good" else sig.astype(np.int32)))
+        handle, n_entries = C.c_void_p(), C.c_int64(0)
+        assert lib.cf_listing_open(os.fsencode(os.path.join(box, "in")), C.byref(handle), C.byref(n_entries), None) == CF_OK
+        try:
+            assert n_entries.value == len(reads)
+            hb, nb = [0], [0]
+            hs, he, ns, ne = [], [], [], []
+            for _name, _n, _kind, hp, non in reads:
+                hs += [a for a, _b in hp]; he += [b for _a, b in hp]; ns += [a for a, _b in non]; ne += [b for _a, b in non]
+                hb.append(len(hs)); nb.append(len(ns))
+            counts = arr64([7, 7, 7, 7])
+            rc = lib.cf_listing_split_npy_int16(handle, 0, len(reads), arr64(hb), arr64(hs) if hs else None, arr64(he) if he else None,
+                                                arr64(nb), arr64(ns) if ns else None, arr64(ne) if ne else None,
+                                                os.fsencode(os.path.join(box, "HP")), os.fsencode(os.path.join(box, "nonHP")), n_threads, counts)
+            cut = [r for r in reads if r[3]]
+            if any(kind != "good" for _name, _n, kind, _hp, _non in cut):
+                assert rc == CF_ERR_INVALID and b".npy" in lib.cf_last_error(), (rc, lib.cf_last_error())
+                return
+            assert rc == CF_OK, (rc, lib.cf_last_error())
+            want = {}
+            for name, _n, _kind, hp, non in cut:                  # in listing order: a later read of the same stem overwrites
+                for k, (a, b) in enumerate(hp + non):
+                    want[("HP" if k < len(hp) else "nonHP", "%s_%d.npy" % (name.split(".")[0], k))] = npy_bytes(signals[name][a:b])
+            stems = [name.split(".")[0] for name, *_ in cut]
+            got = {(d, f): open(os.path.join(box, d, f), "rb").read() for d in ("HP", "nonHP") for f in os.listdir(os.path.join(box, d))}
+            assert set(got) == set(want)
+            if len(set(stems)) == len(stems):
+                assert got == want
+                assert list(counts)[:4] == [len(cut), sum(len(r[3]) for r in cut), sum(len(r[4]) for r in cut),
+                                            sum(len(signals[r[0]][a:b]) for r in cut for a, b in r[3] + r[4])]
+            else:                                               # shared stems: the later read's pieces win where both wrote
+                assert all(got[k] == v for k, v in want.items())
         finally:
             lib.cf_listing_close(handle)
     finally:
@@ -439,6 +515,10 @@ def bad_arguments():
     assert lib.cf_listing_open(os.fsencode(os.path.join(SCRATCH, "no such directory")), C.byref(h), None, None) == CF_ERR_INVALID and not h.value
     assert lib.cf_listing_sizes(None, 0, 0, None, 1) == CF_ERR_INVALID and lib.cf_listing_names(None, 0, 0, None, 0, None, None) == CF_ERR_INVALID
     lib.cf_listing_close(None)
+    assert lib.cf_listing_split_npy_int16(None, 0, 0, None, None, None, None, None, None, None, None, 1, None) == CF_ERR_INVALID
+    assert lib.cf_listing_open(os.fsencode(SCRATCH), C.byref(h), None, None) == CF_OK
+    assert lib.cf_listing_split_npy_int16(h, 0, 0, None, None, None, None, None, None, None, None, 1, None) == CF_OK          # nothing to do
+    lib.cf_listing_close(h)
     assert lib.cf_crc32c(None, 0, 5) == 5 and lib.cf_crc32c(None, 10, 7) == 7 and lib.cf_crc32c(b"123456789", 9, 0) == 0xE3069283
 
 
@@ -450,4 +530,5 @@ if __name__ == "__main__":
     fuzz_listing()
     fuzz_listing_loader()
     fuzz_crc()
+    fuzz_split()
     print("fuzz ok")

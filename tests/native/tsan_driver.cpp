@@ -70,6 +70,36 @@ static void exercise(const std::string& dir, int n_files, int rounds) {
         int64_t total2 = -1;
         CHECK(cf_load_npy_int16(paths.data(), pb.data(), n, out2.data(), cap, lengths.data(), &total2, threads) == CF_OK && total2 == total);
         CHECK(memcmp(out.data(), out2.data(), (size_t)total * 2) == 0);
+        // the split step over the same listing: two HP rows and one non-HP row per read (every third read has none and is skipped),
+        // pieces written by the pool; counts add up and a piece holds the slice
+        if (r < 4) {
+            const std::string hp = dir + "_HP", non = dir + "_nonHP";      // beside the input directory: its listing stays as it is
+            mkdir(hp.c_str(), 0755);
+            mkdir(non.c_str(), 0755);
+            std::vector<int64_t> hb((size_t)n + 1, 0), nbnd((size_t)n + 1, 0), hs, he, ns, ne;
+            int64_t want_reads = 0, want_samples = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t len = lengths[(size_t)i];
+                if (i % 3 != 2) {
+                    hs.push_back(0); he.push_back(len / 2); hs.push_back(-5); he.push_back(len + 9);
+                    ns.push_back(len / 2); ne.push_back(len);
+                    ++want_reads;
+                    want_samples += len / 2 + std::min<int64_t>(5, len) + (len - len / 2);
+                }
+                hb[(size_t)i + 1] = (int64_t)hs.size();
+                nbnd[(size_t)i + 1] = (int64_t)ns.size();
+            }
+            int64_t counts[4] = {-1, -1, -1, -1};
+            CHECK(cf_listing_split_npy_int16(l, 0, n, hb.data(), hs.data(), he.data(), nbnd.data(), ns.data(), ne.data(), hp.c_str(), non.c_str(),
+                                             threads, counts) == CF_OK);
+            CHECK(counts[0] == want_reads && counts[1] == 2 * want_reads && counts[2] == want_reads && counts[3] == want_samples);
+            cf_loader::Item piece;
+            const std::string first = std::string(names.data() + nb[0]);
+            const std::string rel = first.substr(0, first.find('.')) + "_0.npy";
+            const int dfd = open(hp.c_str(), O_RDONLY | O_DIRECTORY);
+            CHECK(dfd >= 0 && cf_loader::slurp(dfd, rel.c_str(), piece) && piece.count == lengths[0] / 2);
+            close(dfd);
+        }
     }
     cf_listing_close(l);
 }

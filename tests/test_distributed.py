@@ -351,9 +351,9 @@ def _pipeline_worker(rank, world, port, tmpdir, n_reads, out_name, break_setup):
         import errno
         from catfish_amd import split
 
-        def no_space_for_chunks(dest_name, signal, s0, s1):
-            raise OSError(errno.ENOSPC, "No space left on device", dest_name)
-        split._write_chunk = no_space_for_chunks
+        def no_space_for_chunks(table, listing, lo, hp_dir, nonhp_dir, n_threads=None):
+            raise OSError(errno.ENOSPC, "No space left on device", hp_dir)
+        split.split_listing = no_space_for_chunks                          # (what cf_listing_split_npy_int16's CF_ERR_IO becomes)
     if break_setup == "short":                                             # every pwrite stops after 7 bytes
         real_pwrite = os.pwrite
         os.pwrite = lambda fd, data, offset: real_pwrite(fd, bytes(data[:7]), offset)

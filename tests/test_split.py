@@ -140,3 +140,100 @@ def test_npy_header_is_numpys_for_every_length_class():
         buf = io.BytesIO()
         np.lib.format.write_array_header_1_0(buf, a)
         assert split.npy_header(n) == buf.getvalue()
+
+
+def _table_from_cases(cases):
+    hb, nb, hs, he, ns, ne, lens = [0], [0], [], [], [], [], []
+    for c in cases:
+        hs += [a for a, _b in c["hp"]]
+        he += [b for _a, b in c["hp"]]
+        ns += [a for a, _b in c["nonhp"]]
+        ne += [b for _a, b in c["nonhp"]]
+        hb.append(len(hs))
+        nb.append(len(ns))
+        lens.append(c["len_read"])
+    return chunks.ChunkTable(lens, hb, hs, he, nb, ns, ne)
+
+
+def test_native_split_of_a_listing_block_writes_the_same_files_as_the_python_loop(golden, tmp_path):
+    """``cf_listing_split_npy_int16`` (csrc/split_host.hpp; host code of the C-ABI library, no GPU) over a directory holding the golden
+    cases as ``.npy`` reads -- edge slices, several dots, an empty stem --, plus reads WITHOUT homopolymer rows (skipped, like the
+    reference's ``for read in hp_dict``) that are not even int16 vectors (never opened): same names, same bytes as ``split_reads``'
+    Python loop and as the reference-executed goldens; a block [lo, hi) inside the listing; counts."""
+    from catfish_amd import sharding
+    doc, arrays = golden
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    cases = []
+    for i, c in enumerate(doc):
+        if not c["name"].endswith(".fast5"):
+            continue                                               # (a name without extension is not a .npy read: general loop only)
+        name = _npy(c["name"])
+        np.save(reads / name, arrays["signal_%d" % i])
+        cases.append(dict(c, name=name, index=i))
+    (reads / "zz_no_hp.npy").write_bytes(b"not a numpy file at all")          # no HP rows: never read
+    cases.append({"name": "zz_no_hp.npy", "len_read": 10, "hp": [], "nonhp": [[0, 10]], "index": None})
+    np.save(reads / "aa_no_hp.npy", np.arange(6, dtype=np.int32))
+    cases.append({"name": "aa_no_hp.npy", "len_read": 6, "hp": [], "nonhp": [[0, 6]], "index": None})
+    cases.sort(key=lambda c: os.fsencode(c["name"]))
+    listing = sharding.DirListing(str(reads))
+    assert listing.names() == [c["name"] for c in cases]
+    table = _table_from_cases(cases)
+    paths = [str(reads / c["name"]) for c in cases]
+    for d in ("n/HP", "n/nonHP", "p/HP", "p/nonHP", "b/HP", "b/nonHP"):
+        (tmp_path / d).mkdir(parents=True)
+    native = split.split_listing(table, listing, 0, str(tmp_path / "n/HP"), str(tmp_path / "n/nonHP"), n_threads=3)
+    python = split.split_reads(table, paths, str(tmp_path / "p/HP"), str(tmp_path / "p/nonHP"))
+    assert native == python and native["reads"] == len(cases) - 2
+    for d in ("HP", "nonHP"):
+        names = sorted(os.listdir(tmp_path / "n" / d))
+        assert names == sorted(os.listdir(tmp_path / "p" / d)) and names
+        assert all((tmp_path / "n" / d / f).read_bytes() == (tmp_path / "p" / d / f).read_bytes() for f in names)
+    for c in cases:                                                # ... and the goldens themselves
+        for j, (folder, name) in enumerate(doc[c["index"]]["files"] if c["index"] is not None else []):
+            assert (tmp_path / "n" / folder / _npy(name)).read_bytes() == _saved(arrays["out_%d_%d" % (c["index"], j)])
+    # a block inside the listing: rows of the table belong to entries [lo, lo + len)
+    lo, hi = 3, 9
+    sub = table.take(np.arange(lo, hi))
+    part = split.split_reads(sub, paths[lo:hi], str(tmp_path / "b/HP"), str(tmp_path / "b/nonHP"), listing=listing, lo=lo)
+    assert part["reads"] == sum(1 for c in cases[lo:hi] if c["hp"])
+    stems = {c["name"].split(".")[0] for c in cases[lo:hi] if c["hp"]}
+    assert {f.rsplit("_", 1)[0] for f in os.listdir(tmp_path / "b/HP")} == stems
+    assert all((tmp_path / "b/HP" / f).read_bytes() == (tmp_path / "n/HP" / f).read_bytes() for f in os.listdir(tmp_path / "b/HP"))
+    listing.close()
+
+
+def test_native_split_refuses_what_it_cannot_read_and_reports_io_errors(tmp_path):
+    """A read WITH homopolymer rows that is not an int16 ``.npy`` vector: ValueError naming it from ``split_listing``, and
+    ``split_reads`` then takes the whole block through the general loop (which reads int32 codes, ``.npz`` and ``.bin`` too).  An output
+    directory that does not exist: OSError with the system's reason (an exception aborts the run, split_f5.py:23-32)."""
+    from catfish_amd import sharding
+    reads = tmp_path / "reads"
+    reads.mkdir()
+    sig = np.arange(100, dtype=np.int16)
+    np.save(reads / "a.npy", sig)
+    np.save(reads / "b.npy", sig.astype(np.int32))                  # codes in int32: infer.load_dac reads them, the native pool does not
+    np.savez(reads / "c.npz", raw=sig)
+    listing = sharding.DirListing(str(reads))
+    table = _table_from_cases([{"len_read": 100, "hp": [[0, 40]], "nonhp": [[40, 100]]}] * 3)
+    paths = [str(reads / n) for n in ("a.npy", "b.npy", "c.npz")]
+    for d in ("HP", "nonHP"):
+        (tmp_path / d).mkdir()
+    with pytest.raises(ValueError, match="c.npz"):
+        split.split_listing(table, listing, 0, str(tmp_path / "HP"), str(tmp_path / "nonHP"))
+    two = table.take(np.arange(2))
+    with pytest.raises(ValueError, match="b.npy"):
+        split.split_listing(two, listing, 0, str(tmp_path / "HP"), str(tmp_path / "nonHP"))
+    done = split.split_reads(table, paths, str(tmp_path / "HP"), str(tmp_path / "nonHP"), listing=listing, lo=0)
+    assert done == {"reads": 3, "files_hp": 3, "files_nonhp": 3, "samples": 300}
+    for stem in "abc":
+        assert np.array_equal(np.load(tmp_path / "HP" / (stem + "_0.npy")), sig[:40])
+        assert np.array_equal(np.load(tmp_path / "nonHP" / (stem + "_1.npy")), sig[40:])
+    one = table.take(np.arange(1))
+    with pytest.raises(OSError, match="nowhere"):
+        split.split_listing(one, listing, 0, str(tmp_path / "nowhere"), str(tmp_path / "nonHP"))
+    (tmp_path / "HP" / "a_0.npy").unlink()
+    (tmp_path / "HP" / "a_0.npy").mkdir()                           # the piece's name is taken by a directory: open() fails
+    with pytest.raises(OSError, match="a_0.npy"):
+        split.split_listing(one, listing, 0, str(tmp_path / "HP"), str(tmp_path / "nonHP"))
+    listing.close()
