@@ -51,6 +51,11 @@ class NativeTrainStep(object):
         self._layout()
         self._rehome()
         self._bufs = None
+        # weight gradients of layer L on a second stream, next to the backward recurrence of layer L - 1 (which needs only dX of layer
+        # L): at the reference's batch of 256 windows the step is a chain of launches of 16 tiles on 256 CUs, and the twelve-wave wgrad
+        # workgroups fit beside the four-wave recurrence ones.  A fork / join per layer in the captured graph.
+        self.overlap_wgrad = True
+        self._side = None
 
     # ------------------------------------------------------------------ flat layout
     def _layout(self):
@@ -141,9 +146,10 @@ class NativeTrainStep(object):
         b["y_drop"] = [torch.empty(tiles, T, 8, 64, 4, **f32) for _ in range(self.n_layers)] if self.keep_prob < 1.0 else None
         b["dy_head"] = torch.empty(tiles, T, 8, 64, 4, **f32)
         b["dx"] = [torch.empty(2, tiles, T, c // 16, 64, 4, **f32) for c in self.cins]
-        b["da"] = torch.empty(tiles, T, 2, 12, 64, 4, **f32)
+        # per layer: layer L's pre-activation gradients and partial sums are still being read (wgrad, side stream) while layer L - 1's are written
+        b["da"] = [torch.empty(tiles, T, 2, 12, 64, 4, **f32) for _ in self.cins]
         b["head_ws"] = torch.empty(int(lib.cf_train_head_workspace_floats(self.handle, npad)), **f32)
-        b["wgrad_ws"] = torch.empty(max(int(lib.cf_gru_wgrad_workspace_floats(self.handle, c, npad)) for c in self.cins), **f32)
+        b["wgrad_ws"] = [torch.empty(int(lib.cf_gru_wgrad_workspace_floats(self.handle, c, npad)), **f32) for c in self.cins]
         b["res_ws"] = torch.empty(int(lib.cf_res_train_workspace_floats(self.n_blocks, n)), **f32)
         b["loss"] = torch.zeros(1, **f32)
         return b
@@ -188,6 +194,12 @@ class NativeTrainStep(object):
         N.check(lib.cf_train_head(h, _p(cur), _p(pf[ho:ho + 128]), _p(pf[ho + 128:ho + 129]), _p(b["y"]), n, _p(b["dy_head"]), None,
                                   _p(b["head_ws"]), int(b["head_ws"].numel()), _p(gf[ho:ho + 129]), _p(b["loss"]), stream))
         # ---- backward through the biGRU layers
+        main = torch.cuda.current_stream(self.dev)
+        side = None
+        if self.overlap_wgrad:
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.dev)
+            side = self._side
         g0, g1 = b["dy_head"], None
         for layer in range(self.n_layers - 1, -1, -1):
             cin = self.cins[layer]
@@ -195,15 +207,21 @@ class NativeTrainStep(object):
             dx = b["dx"][layer]
             N.check(lib.cf_gru_train_backward_dropout(h, cin, _p(self.packed[bo:bo + bn]), _p(b["y_frag"][layer]), _p(b["stash"][layer]),
                                                       _p(g0), None if g1 is None else _p(g1), None if drop is None else _p(drop[layer]),
-                                                      _p(dx), _p(b["da"]), npad, kp if in_kernel else 1.0, self.seed, layer, step_ptr,
+                                                      _p(dx), _p(b["da"][layer]), npad, kp if in_kernel else 1.0, self.seed, layer, step_ptr,
                                                       stream))
             go = self.gru_off[layer]
-            N.check(lib.cf_gru_train_wgrad(h, cin, _p(inputs[layer]), _p(b["y_frag"][layer]), _p(b["stash"][layer]), _p(b["da"]), npad,
-                                           _p(b["wgrad_ws"]), int(b["wgrad_ws"].numel()), _p(gf[go:]), stream))
+            wstream = stream
+            if side is not None:
+                side.wait_stream(main)                      # fork: everything up to this layer's backward recurrence
+                wstream = C.c_void_p(side.cuda_stream)
+            N.check(lib.cf_gru_train_wgrad(h, cin, _p(inputs[layer]), _p(b["y_frag"][layer]), _p(b["stash"][layer]), _p(b["da"][layer]), npad,
+                                           _p(b["wgrad_ws"][layer]), int(b["wgrad_ws"][layer].numel()), _p(gf[go:]), wstream))
             g0, g1 = dx[0], dx[1]
         d_out = frag_to_nat(g0 + g1)[:n].contiguous()
         N.check(lib.cf_res_train_backward(h, self.n_blocks, _p(pf), _p(b["x"]), _p(b["z"]), _p(d_out), _p(b["res_ws"]),
                                           int(b["res_ws"].numel()), _p(gf), n, stream))
+        if side is not None:
+            main.wait_stream(side)                          # join: the optimizer reads every gradient
         # ---- optimizer over every variable + re-tiling of the biGRU weights
         if update:
             N.check(lib.cf_opt_step(h, self.kind, _p(pf), _p(gf), _p(self.s1), _p(self.s2), self.n_total - 1, float(self.opt.lr),

@@ -13,15 +13,22 @@ for S in $STAGES; do
   case $S in
     tests) timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1 || { echo "gpu tests FAILED" >> $OUT/commit.txt; tail -40 $OUT/gpu_tests.log; exit 1; } ;;
     bench) timeout -k 10 700 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo "bench FAILED" >> $OUT/commit.txt; tail -20 $OUT/bench_default.err; exit 1; } ;;
-    train)   # config 5 (the training step): host/device breakdown of a step + rocprofv3 kernel trace of the same command, at 256 and 4096 windows
+    train)   # config 5 (the training step): host/device breakdown of a step + rocprofv3 kernel trace of the same command, at 256 and 4096 windows,
+             # weight gradients beside the next layer's backward (default) and in round 5's order (--no-overlap), interleaved twice
       for B in 256 4096; do
-        timeout -k 10 300 python3 tools/bench_train.py --batch $B --profile-only --steps 200 > $OUT/train_parts_$B.json 2> $OUT/train_parts_$B.err \
-          || { echo "train parts $B FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_parts_$B.err; exit 1; }
-        rm -rf /tmp/kt_train_$B
-        timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_train_$B -o kt -- python3 tools/bench_train.py --batch $B --profile-only --steps 200 \
-          > $OUT/train_prof_$B.json 2> $OUT/train_prof_$B.err || { echo "train prof $B FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_prof_$B.err; exit 1; }
-        cp $(find /tmp/kt_train_$B -name "*kernel_stats.csv" | head -1) $OUT/train_kernel_stats_$B.csv
-        python3 tools/train_gap.py $OUT/train_kernel_stats_$B.csv $OUT/train_prof_$B.json $OUT/train_parts_$B.json > $OUT/train_gap_$B.json
+        for R in 1 2; do for V in overlap serial; do
+          F=""; [ $V = serial ] && F="--no-overlap"
+          timeout -k 10 300 python3 tools/bench_train.py --batch $B --profile-only --steps 300 $F > $OUT/train_parts_${B}_${V}_$R.json 2> $OUT/train_parts_$B.err \
+            || { echo "train parts $B $V FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_parts_$B.err; exit 1; }
+        done; done
+        for V in overlap serial; do
+          F=""; [ $V = serial ] && F="--no-overlap"
+          rm -rf /tmp/kt_train_$B
+          timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_train_$B -o kt -- python3 tools/bench_train.py --batch $B --profile-only --steps 300 $F \
+            > $OUT/train_prof_${B}_$V.json 2> $OUT/train_prof_$B.err || { echo "train prof $B FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_prof_$B.err; exit 1; }
+          cp $(find /tmp/kt_train_$B -name "*kernel_stats.csv" | head -1) $OUT/train_kernel_stats_${B}_$V.csv
+          python3 tools/train_gap.py $OUT/train_kernel_stats_${B}_$V.csv $OUT/train_prof_${B}_$V.json $OUT/train_parts_${B}_${V}_2.json > $OUT/train_gap_${B}_$V.json
+        done
       done ;;
     rehearse6)   # the N > 1 launch path at configs[2]'s per-rank size, SIX ranks on ONE card (the box allows at most 6 processes on its GPU): a rehearsal (value null), never a measurement
       CATFISH_BENCH_DEVICE=0 CATFISH_DEVICE=0 CATFISH_RCCL_PROBE_TIMEOUT_S=60 timeout -k 10 1000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 6 \

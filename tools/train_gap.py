@@ -22,7 +22,7 @@ def main():
     with open(plain) as fh:
         free = json.loads(fh.read().strip().splitlines()[-1])
     opt = [r for r in rows if "opt_step" in r["Name"]]
-    n_steps = int(opt[0]["Calls"]) if opt else 5 + 2 * under["steps"]
+    n_steps = int(opt[0]["Calls"]) if opt else 2 * under["steps"]
     kernels, total_ns = [], 0.0
     for r in rows:
         calls, tot = int(r["Calls"]), float(r["TotalDurationNs"])
@@ -34,7 +34,7 @@ def main():
     ksum_ms = total_ns / n_steps / 1e6
     wall = free["ms_per_step"]
     print(json.dumps({
-        "batch": free["batch"], "steps_traced": n_steps, "launches_per_step": round(sum(k["launches_per_step"] for k in kernels), 1),
+        "batch": free["batch"], "overlap_wgrad": free.get("overlap_wgrad"), "steps_traced": n_steps, "launches_per_step": round(sum(k["launches_per_step"] for k in kernels), 1),
         "kernel_sum_ms_per_step": ksum_ms, "wall_ms_per_step": wall, "wall_ms_per_step_under_profiler": under["ms_per_step"],
         "graph_device_ms": free["parts_ms"]["graph_device_ms"], "parts_ms": free["parts_ms"],
         "no_kernel_share_of_wall": 1.0 - ksum_ms / wall, "gaps_inside_graph_ms": free["parts_ms"]["graph_device_ms"] - ksum_ms,
