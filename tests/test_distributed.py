@@ -3,6 +3,7 @@
 The per-shard inference callable is injected; here it is backed by the CPU oracle (tests may use
 the oracle as a stand-in engine -- the product path passes the HIP engine).
 """
+import json
 import os
 import socket
 import sys
@@ -574,3 +575,38 @@ def test_contiguous_shards_tile_in_order_and_balance():
     assert sharding.shard_contiguous([1, 1], 4) == [[], [0], [], [1]] and sharding.shard_contiguous([], 3) == [[], [], []]
     with pytest.raises(ValueError):
         sharding.shard_contiguous([1], 0)
+
+
+# ------------------------------------------------------------------ bench.py: RCCL is a bounded probe beside the host group
+def _probe_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo")
+    t0 = time.time()
+    res = bench.probe_rccl(dist, torch, 0, timeout_s=20)
+    dist.barrier()                                                         # the host group still works after a failed probe
+    one = torch.ones(1)
+    dist.all_reduce(one)
+    os.environ["CATFISH_RCCL_PROBE"] = "0"
+    skipped = bench.probe_rccl(dist, torch, 0)
+    open(os.path.join(tmpdir, "probe.rank%d" % rank), "w").write(json.dumps({"res": res, "seconds": time.time() - t0, "sum": float(one.item()),
+                                                                              "skipped": skipped}))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_rccl_probe_failure_costs_a_note_not_the_run(tmp_path):
+    """the timing barrier of bench.py is on the host (gloo) group whatever RCCL does, and RCCL is brought up as a
+    PROBE over a second group with a short timeout.  Here (no GPU: the RCCL group cannot come up) the probe must fail on every rank
+    with a recorded error within its timeout, every rank must agree it failed, and the gloo group must keep working."""
+    import torch.multiprocessing as mp
+    mp.spawn(_probe_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = json.loads((tmp_path / ("probe.rank%d" % r)).read_text())
+        assert got["res"]["ok"] is False and got["res"]["error"] and got["res"]["ranks_seen"] in (None, 1, 2)
+        assert got["res"]["timeout_s"] == 20 and got["seconds"] < 60 and got["sum"] == 2.0
+        assert got["skipped"]["ok"] is False and "skipped" in got["skipped"]["error"]
