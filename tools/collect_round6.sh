@@ -30,6 +30,12 @@ for S in $STAGES; do
           python3 tools/train_gap.py $OUT/train_kernel_stats_${B}_$V.csv $OUT/train_prof_${B}_$V.json $OUT/train_parts_${B}_${V}_2.json > $OUT/train_gap_${B}_$V.json
         done
       done ;;
+    pinab)   # training batches through pinned staging (default) against pageable copies (round 5), interleaved
+      for B in 256 4096; do for R in 1 2 3; do for V in pinned pageable; do
+        F=""; [ $V = pageable ] && F="--pageable"
+        timeout -k 10 300 python3 tools/bench_train.py --batch $B --profile-only --steps 300 $F > $OUT/train_pin_${B}_${V}_$R.json 2> $OUT/train_pin.err \
+          || { echo "pinab $B $V FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_pin.err; exit 1; }
+      done; done; done ;;
     rehearse6)   # the N > 1 launch path at configs[2]'s per-rank size, SIX ranks on ONE card (the box allows at most 6 processes on its GPU): a rehearsal (value null), never a measurement
       CATFISH_BENCH_DEVICE=0 CATFISH_DEVICE=0 CATFISH_RCCL_PROBE_TIMEOUT_S=60 timeout -k 10 1000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 6 \
         --master-addr 127.0.0.1 --master-port 29506 bench.py --gpus 6 --steps 20 --warmup 5 --reads-per-rank 12500 \
