@@ -56,7 +56,6 @@ class NativeTrainStep(object):
         # workgroups fit beside the four-wave recurrence ones.  A fork / join per layer in the captured graph.
         self.overlap_wgrad = True
         self._side = None
-        self.pinned_batches = True
 
     # ------------------------------------------------------------------ flat layout
     def _layout(self):
@@ -230,26 +229,13 @@ class NativeTrainStep(object):
         return b["loss"]
 
     def load_batch(self, b, x, y):
-        """The batch into the step's static device buffers, through PINNED staging: a copy from pageable numpy memory is synchronous
-        (33 us of a 0.83 ms step at 256 windows, measured in round 6), from pinned memory it is queued and the launch of the step
-        follows at once."""
+        """The batch into the step's static device buffers.  (Pinned staging was measured in round 6 and dropped: 0.764-0.781 ms per
+        256-window step against 0.754-0.762 with these plain copies, `profiles/r06_train_pinned_vs_pageable.log` -- the extra host copy
+        and event cost more than the synchronous 36 KB copies.)"""
         torch = self.torch
         n = b["n"]
-        if not self.pinned_batches:
-            b["x"].copy_(torch.as_tensor(np.asarray(x), dtype=torch.float32).reshape(n, T), non_blocking=True)
-            b["y"][:n].copy_(torch.as_tensor(np.asarray(y), dtype=torch.float32).reshape(n, T), non_blocking=True)
-            return
-        if "pin" not in b:
-            b["pin"] = torch.empty(2, n, T, dtype=torch.float32).pin_memory()
-            b["pin_free"] = torch.cuda.Event()
-        else:
-            b["pin_free"].synchronize()                     # the copies that last read the staging buffer are done
-        pin = b["pin"].numpy()
-        pin[0] = np.asarray(x, dtype=np.float32).reshape(n, T)
-        pin[1] = np.asarray(y, dtype=np.float32).reshape(n, T)
-        b["x"].copy_(b["pin"][0], non_blocking=True)
-        b["y"][:n].copy_(b["pin"][1], non_blocking=True)
-        b["pin_free"].record(torch.cuda.current_stream(self.dev))
+        b["x"].copy_(torch.as_tensor(np.asarray(x), dtype=torch.float32).reshape(n, T), non_blocking=True)
+        b["y"][:n].copy_(torch.as_tensor(np.asarray(y), dtype=torch.float32).reshape(n, T), non_blocking=True)
 
     def dropout_scales(self, n, keep_prob=None):
         """The mask / keep_prob tensors the kernels apply at the CURRENT optimizer step, as {(layer, "fw"|"bw"): 0/1 array

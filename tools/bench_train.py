@@ -18,7 +18,7 @@ from catfish_amd.training import Trainer  # noqa: E402
 import bench  # noqa: E402
 
 
-def profile_only(B, steps, overlap=True, pinned=True):
+def profile_only(B, steps, overlap=True):
     """One trainer, ``steps`` steps, and where a step's wall time goes: the host copies of the batch (``load_batch``: numpy -> static
     device buffers), the graph launch, the device time of the replayed graph (HIP events on the stream it runs on) and the
     loss read-back that ends the step.  Prints one JSON line."""
@@ -29,7 +29,6 @@ def profile_only(B, steps, overlap=True, pinned=True):
     y = np.repeat((np.arange(B) % 2)[:, None], 35, axis=1).astype(np.float32)
     tr = Trainer(w, 3, 2, "Adam", 1e-3, keep_prob=0.8, device="cuda", seed=0)
     tr.step_impl.overlap_wgrad = bool(overlap)
-    tr.step_impl.pinned_batches = bool(pinned)
     tw = time.perf_counter()
     while time.perf_counter() - tw < 0.5:                        # clocks up
         tr.train_step(x, y)
@@ -57,7 +56,7 @@ def profile_only(B, steps, overlap=True, pinned=True):
         float(sloss.detach())
         parts["loss_readback_ms"] += time.perf_counter() - t
         parts["graph_device_ms"] += e0.elapsed_time(e1) * 1e-3
-    print(json.dumps({"batch": B, "steps": steps, "overlap_wgrad": bool(overlap), "pinned_batches": bool(pinned), "ms_per_step": wall * 1e3, "windows_per_s": B / wall,
+    print(json.dumps({"batch": B, "steps": steps, "overlap_wgrad": bool(overlap), "ms_per_step": wall * 1e3, "windows_per_s": B / wall,
                       "parts_ms": {k: v / steps * 1e3 for k, v in parts.items()},
                       "what": "parts measured in a second loop with a synchronise after the batch copies: load_batch = numpy -> static device "
                               "buffers (pageable H2D), replay_call = host time of hipGraphLaunch, graph_device = HIP events around the "
@@ -74,11 +73,10 @@ def main():
                          "to a whole step: kernel-time sum / steps against wall per step = the launch-gap share)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--no-overlap", action="store_true", help="profile-only: weight gradients on the main stream (round 5's order)")
-    ap.add_argument("--pageable", action="store_true", help="profile-only: batches copied from pageable memory (round 5)")
     args = ap.parse_args()
     B = args.batch
     if args.profile_only:
-        return profile_only(B, args.steps, overlap=not args.no_overlap, pinned=not args.pageable)
+        return profile_only(B, args.steps, overlap=not args.no_overlap)
     w = bench.load_weights()
     reads = bench.make_reads(max(8, B // 100 + 1), seed=5).reshape(-1, 35)
     rng = np.random.default_rng(0)
