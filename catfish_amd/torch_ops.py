@@ -85,12 +85,16 @@ def pack_weights(weights, n_layers=3, layer_size=64, n_layers_res=2, layer_size_
     return torch.from_numpy(np.concatenate(parts))
 
 
-def unpack_weights(packed):
-    """The inverse: flat tensor -> (dict of arrays, dict(n_layers, layer_size, n_layers_res, layer_size_res)); ValueError when the
-    tensor is not one ``pack_weights`` made (dtype, device, magic, length)."""
+def _check_packed(packed):
     import torch
     if not isinstance(packed, torch.Tensor) or packed.dtype != torch.float32 or packed.dim() != 1 or packed.is_cuda:
         raise ValueError("packed_weights must be the flat float32 CPU tensor pack_weights() returns")
+
+
+def unpack_weights(packed):
+    """The inverse: flat tensor -> (dict of arrays, dict(n_layers, layer_size, n_layers_res, layer_size_res)); ValueError when the
+    tensor is not one ``pack_weights`` made (dtype, device, magic, length)."""
+    _check_packed(packed)
     flat = packed.detach().contiguous().numpy()
     if flat.shape[0] < HEADER or flat[0] != MAGIC:
         raise ValueError("packed_weights does not start with the catfish header")
@@ -120,6 +124,7 @@ def _content_key(packed, device_index):
     passing the same live tensor, unmodified as far as torch's version counter sees, the look-up costs two dict reads."""
     import hashlib
     import weakref
+    _check_packed(packed)                                     # (before anything is hashed: a CUDA or float64 tensor is a ValueError, as ever)
     seen = _SEEN.get(id(packed))
     if seen is not None and seen[0]() is packed and seen[1] == packed._version:
         return seen[2] + (int(device_index),)

@@ -781,6 +781,9 @@ def test_torch_operator_keys_its_engines_on_the_weights_content(monkeypatch):
     a[-1] = 0.5                                                      # in place on a live tensor: torch's version counter moves
     assert ops._engine_for(a, 0).mark == 0.5 and ops._engine_for(twin, 0).mark == 0.25
     assert not ops._SEEN or all(ref() is not None for ref, _v, _k in ops._SEEN.values())      # dead tensors left the identity table
+    for broken in (a.double(), a.reshape(1, -1), "not a tensor"):                # refused before anything is hashed or built
+        with pytest.raises(ValueError, match="flat float32 CPU tensor"):
+            ops._engine_for(broken, 0)
     ops.clear_engine_cache()
     assert not ops._ENGINES and not ops._SEEN
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round-6 measurements the docs cite, written under gpurun_out/round6/ (copy what is judged into profiles/).
 # usage:  bash tools/collect_round6.sh <commit> [stage ...]
-#   stages: tests bench train rehearse5 prof streams   (default: tests bench train)
+#   stages: tests bench train rehearse5 prof streams traffic   (default: tests bench train)
 COMMIT=${1:-unknown}; shift
 STAGES=${@:-tests bench train}
 ROOT="$GRAFT_REPO_ROOT"
@@ -34,6 +34,12 @@ for S in $STAGES; do
       CATFISH_BENCH_DEVICE=0 CATFISH_DEVICE=0 CATFISH_RCCL_PROBE_TIMEOUT_S=60 timeout -k 10 1000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 5 \
         --master-addr 127.0.0.1 --master-port 29506 bench.py --gpus 5 --steps 20 --warmup 5 --reads-per-rank 20000 \
         > $OUT/bench_5ranks_100k_files_one_gpu.json 2> $OUT/bench_5ranks.err || { echo "rehearsal FAILED" >> $OUT/commit.txt; tail -30 $OUT/bench_5ranks.err; exit 1; } ;;
+    traffic)   # counter traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and MFMA-busy of the fp32 headline kernels at this commit
+      bash tools/collect_traffic.sh $COMMIT fp32 > $OUT/traffic_fp32.log 2>&1 || { echo "traffic FAILED" >> $OUT/commit.txt; tail -20 $OUT/traffic_fp32.log; exit 1; }
+      cp gpurun_out/traffic_fp32.json $OUT/ 2>/dev/null
+      PREC=fp32 bash tools/pmc_pass.sh SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVE_CYCLES > $OUT/pmc_fp32_a.jsonl 2>&1 \
+        || { echo "pmc FAILED" >> $OUT/commit.txt; tail -20 $OUT/pmc_fp32_a.jsonl; exit 1; }
+      python3 tools/merge_pmc.py $COMMIT fp32=$OUT/pmc_fp32_a.jsonl > $OUT/pmc.json 2>> $OUT/traffic_fp32.log || true ;;
     prof)
       for P in fp32; do
         rm -rf /tmp/kt_$P
