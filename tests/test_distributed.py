@@ -577,6 +577,24 @@ def test_contiguous_shards_tile_in_order_and_balance():
         sharding.shard_contiguous([1], 0)
 
 
+@pytest.mark.timeout(300)
+def test_more_ranks_than_reads_go_through_every_stage(tmp_path):
+    """Eight ranks, five reads: three ranks own no file at all and still take part in the listing, the agreement on the documents
+    and the split step (an empty block: nothing to cut, no native call) -- the job ends on every rank with the same totals, and the
+    output equals one rank's."""
+    import torch.multiprocessing as mp
+    _write_reads(str(tmp_path / "reads"), 5)
+    mp.spawn(_pipeline_worker, args=(8, _free_port(), str(tmp_path), 5, "outmany", None), nprocs=8, join=True)
+    mp.spawn(_pipeline_worker, args=(1, _free_port(), str(tmp_path), 5, "outone", None), nprocs=1, join=True)
+    assert all((tmp_path / ("outmany.rank%d" % r)).read_text().endswith("returned 5 reads, table None") for r in range(8))
+    for rel in ("hp_positions.json", "nonhp_positions.json"):
+        assert (tmp_path / "outmany" / "TEMP" / rel).read_bytes() == (tmp_path / "outone" / "TEMP" / rel).read_bytes()
+    for d in ("HP", "nonHP"):
+        many = {f: (tmp_path / "outmany" / "TEMP" / d / f).read_bytes() for f in os.listdir(tmp_path / "outmany" / "TEMP" / d)}
+        one = {f: (tmp_path / "outone" / "TEMP" / d / f).read_bytes() for f in os.listdir(tmp_path / "outone" / "TEMP" / d)}
+        assert many == one and many
+
+
 # ------------------------------------------------------------------ bench.py: RCCL is a bounded probe beside the host group
 def _probe_worker(rank, world, port, tmpdir):
     sys.path.insert(0, ROOT)
