@@ -1017,6 +1017,36 @@ def test_cli_two_ranks_share_one_gpu(tmp_path, ckpt_weights):
             assert name not in hp
 
 
+@pytest.mark.timeout(300)
+def test_rccl_probe_of_the_bench_succeeds_with_one_rank(tmp_path):
+    """bench.py brings RCCL ("nccl" on ROCm) up as a PROBE beside its host group (`bench.probe_rccl`).  Two ranks on this box's ONE card
+    cannot succeed ("Duplicate GPU detected" -- the rehearsal lines record it); ONE rank can: a second process group over RCCL, one
+    all-reduce of a device scalar, blocking wait, destroyed again -- the success path of the probe (`ok`, `ranks_seen` = world) and
+    proof that this image's RCCL loads and runs a collective on the card.  In a child process: a process group is per process."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "import bench\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "res = bench.probe_rccl(dist, torch, 0, timeout_s=120)\n"
+        "one = torch.ones(1); dist.all_reduce(one)\n"
+        "dist.destroy_process_group()\n"
+        "print('PROBE ' + json.dumps(res))\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
+                         env=env, timeout=250, cwd=str(tmp_path))
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("PROBE ")]
+    assert run.returncode == 0 and lines, run.stdout[-3000:]
+    res = json.loads(lines[-1][len("PROBE "):])
+    assert res["ok"] is True and res["ranks_seen"] == 1 and res["error"] is None and res["seconds"] < 120, res
+
+
 def test_configs1_at_full_size_is_invariant_to_the_launch_size(ckpt_weights):
     """BASELINE configs[1] at its full size -- 10 000 synthetic 4096-sample reads, fp32 -- which the oracle cannot follow
     (it classifies ~75 k samples/s per core; this is 41 M): windows are independent, so how many reads share a launch must
