@@ -189,3 +189,35 @@ def test_without_h5py_the_branch_says_what_is_missing(fast5, monkeypatch):
     monkeypatch.setitem(sys.modules, "h5py", None)                                  # import h5py -> ImportError
     with pytest.raises(ImportError, match="needs h5py"):
         infer.load_dac(fast5["path"])
+
+
+def test_converter_writes_the_reads_the_native_loader_takes(fast5, tmp_path):
+    """``python -m catfish_amd.convert``: FAST5 (through the stand-in h5py) -> int16 ``.npy`` holding exactly ``load_dac``'s samples,
+    byte for byte ``numpy.save``; the result goes through the byte-level reader and the library's loader pool; an unreadable file
+    stops the run (or is reported with ``--keep-going``)."""
+    import io
+    from catfish_amd import convert
+    src_dir = os.path.dirname(fast5["path"])
+    out = tmp_path / "npy"
+    done = convert.convert_directory(src_dir, str(out))
+    assert done == {"converted": 1, "samples": 3000, "failed": []}
+    dst = out / "read_ch12.npy"
+    want = fast5["signal"][fast5["first"]:]
+    buf = io.BytesIO()
+    np.save(buf, want)
+    assert dst.read_bytes() == buf.getvalue() and not (out / "read_ch12.npy.part").exists()
+    assert np.array_equal(infer._read_npy_int16(str(dst)), want)                   # the fast path of infer.load_dac takes it
+    from catfish_amd import sharding
+    listing = sharding.DirListing(str(out))
+    assert listing.names() == ["read_ch12.npy"] and listing.sizes(0, 1).tolist() == [len(buf.getvalue())]
+    listing.close()
+    open(os.path.join(src_dir, "zz_garbage.fast5"), "wb").write(b"junk")            # not in the stand-in's registry: h5py cannot open it
+    with pytest.raises(OSError):
+        convert.convert_directory(src_dir, str(out))
+    assert convert.main(["-i", src_dir, "-o", str(out), "--keep-going"]) == 1
+    kept = convert.convert_directory(src_dir, str(out), keep_going=True)
+    assert kept["converted"] == 1 and [n for n, _e in kept["failed"]] == ["zz_garbage.fast5"]
+    # samples that are not int16 codes are refused, not truncated
+    fast5["registry"][fast5["path"]] = _single_read_tree(np.array([0.5, 1.5, 2.5, 70000.0]), 0)
+    with pytest.raises(ValueError, match="int16 DAC codes"):
+        convert.convert_read(fast5["path"], str(out / "x.npy"))
