@@ -1038,7 +1038,8 @@ def test_rccl_probe_of_the_bench_succeeds_with_one_rank(tmp_path):
         "one = torch.ones(1); dist.all_reduce(one)\n"
         "dist.destroy_process_group()\n"
         "print('PROBE ' + json.dumps(res))\n" % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from catfish_amd.cli import free_port
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     run = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
                          env=env, timeout=250, cwd=str(tmp_path))
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("PROBE ")]
