@@ -41,7 +41,7 @@ for S in $STAGES; do
         || { echo "pmc FAILED" >> $OUT/commit.txt; tail -20 $OUT/pmc_fp32_a.jsonl; exit 1; }
       python3 tools/merge_pmc.py $COMMIT fp32=$OUT/pmc_fp32_a.jsonl > $OUT/pmc.json 2>> $OUT/traffic_fp32.log || true ;;
     prof)
-      for P in fp32; do
+      for P in ${PRECS:-fp32}; do
         rm -rf /tmp/kt_$P
         rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$P -o kt -- python3 bench.py --precision $P --no-cpu-baseline --no-extra-precisions --no-sharded-leg > $OUT/bench_prof_$P.json 2>/dev/null
         cp $(find /tmp/kt_$P -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_$P.csv
