@@ -185,6 +185,11 @@ def test_verify_keeps_a_right_guess_and_rebinds_a_wrong_one(tmp_path, monkeypatc
     placement.verify(p, _bdf(6), local_rank=1, local_world=8, sysfs=root)                       # it is the card on the other socket
     assert p["bdf_agrees"] is False and p["rebound_after_gpu_init"] is True and p["bdf"] == _bdf(6)
     assert set(calls[-1]) <= set(range(16, 32)) | set(range(48, 64)) and calls[-1] == p["cpus"]
+    # the real card's locality set is cut among the ranks that SHARE it -- this rank plus the four planned on that socket --,
+    # not among all eight ranks of the node: a fifth of the socket (whole cores), not an eighth
+    assert p["shared_with"] == [1, 4, 5, 6, 7]
+    assert p["cpus"] == placement.slice_for(0, 5, sorted(set(range(16, 32)) | set(range(48, 64))), root)
+    assert len(p["cpus"]) > len(placement.slice_for(1, 8, sorted(set(range(16, 32)) | set(range(48, 64))), root)) or len(p["cpus"]) == 32
     s = placement.summary(p)
     assert s["bdf_from_runtime"] == _bdf(6) and s["rebound_after_gpu_init"] is True and s["n_cpus"] == len(p["cpus"])
     monkeypatch.setattr(placement, "_APPLIED", None)
