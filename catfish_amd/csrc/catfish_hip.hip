@@ -2005,6 +2005,15 @@ extern "C" int cf_gru_train_forward(cf_model* m, int32_t cin, const float* wpack
     return cf_gru_train_forward_dropout(m, cin, wpack, x_frag, y_frag, stash, n_windows, nullptr, 1.f, 0u, 0, nullptr, stream);
 }
 
+// chunks of steps per (tile, direction) of the deferred input-gradient launch (gru_dx_kernel: launch shape only, results do not depend on it)
+// -- about 2.25 workgroups per CU: at the reference's batch (256 windows = 16 tiles) 18 chunks instead of round 5's 7 took the training
+// step from 0.756 to 0.738 ms (profiles/r06_train_dx_chunks.log); few tiles keep one step per workgroup, many keep 7 chunks
+static int dx_chunks(int n_tiles, int n_cu) {
+    if (cf_knob("CATFISH_DX_CHUNKS")) return std::max(1, std::min(atoi(cf_knob("CATFISH_DX_CHUNKS")), CF_T));      // A/B knob for tools/
+    const int want = (9 * std::max(1, n_cu) / 4 + 2 * n_tiles - 1) / (2 * std::max(1, n_tiles));
+    return std::max(7, std::min(CF_T, want));
+}
+
 extern "C" int cf_gru_train_backward_dropout(cf_model* m, int32_t cin, const float* wpack_bwd, const float* y_frag, const float* stash,
                                              const float* dy_frag, const float* dy2_frag, const float* dy_scale, float* dx_frag, float* da,
                                              int64_t n_windows, float keep_prob, uint32_t seed, int32_t layer, const double* step_count,
@@ -2021,22 +2030,23 @@ extern "C" int cf_gru_train_backward_dropout(cf_model* m, int32_t cin, const flo
     if (n_tiles <= m->n_cu) {                // small batch: four waves per tile (latency mode), up to two rounds
         const int gxc = std::min(n_tiles, std::max(1, m->n_cu / 2));
         const int defer = n_tiles <= m->xp_tiles ? 1 : 0;                    // few tiles: dx is formed afterwards on the idle CUs
+        const int dxc = dx_chunks(n_tiles, m->n_cu);
         if (cin == CF_C) {
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<32>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(32) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
                                reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer, drop);
             if (defer)
-                hipLaunchKernelGGL((gru_dx_kernel<32>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
-                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles, cf_xproj_chunks(n_tiles));
+                hipLaunchKernelGGL((gru_dx_kernel<32>), dim3(n_tiles * dxc, 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
+                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles, dxc);
         } else {
             hipLaunchKernelGGL((gru_train_bwd_coop_kernel<128>), dim3(gxc, 2), dim3(256), (gtb_pack_floats(128) + CF_COOP_BWD_XCH_FLOATS) * 4, s,
                                wpack_bwd, reinterpret_cast<const f32x4*>(y_frag), reinterpret_cast<const f32x4*>(stash),
                                reinterpret_cast<const f32x4*>(dy_frag), reinterpret_cast<const f32x4*>(dy2_frag),
                                reinterpret_cast<const f32x4*>(dy_scale), reinterpret_cast<f32x4*>(dx_frag), reinterpret_cast<f32x4*>(da), n_tiles, defer, drop);
             if (defer)
-                hipLaunchKernelGGL((gru_dx_kernel<128>), dim3(n_tiles * cf_xproj_chunks(n_tiles), 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
-                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles, cf_xproj_chunks(n_tiles));
+                hipLaunchKernelGGL((gru_dx_kernel<128>), dim3(n_tiles * dxc, 2), dim3(256), 0, s, wpack_bwd, reinterpret_cast<const f32x4*>(da),
+                                   reinterpret_cast<f32x4*>(dx_frag), n_tiles, dxc);
         }
         HIP_TRY(hipGetLastError());
         return CF_OK;

@@ -30,6 +30,12 @@ for S in $STAGES; do
           python3 tools/train_gap.py $OUT/train_kernel_stats_${B}_$V.csv $OUT/train_prof_${B}_$V.json $OUT/train_parts_${B}_${V}_2.json > $OUT/train_gap_${B}_$V.json
         done
       done ;;
+    dxchunks)   # launch shape of the deferred input-gradient kernel in the training step (results do not depend on it), interleaved
+      rm -f $OUT/train_dx_chunks.log
+      for B in 256 1024; do for R in 1 2 3; do for V in 7 12 18 35; do
+        CATFISH_DEBUG_KNOBS=1 CATFISH_DX_CHUNKS=$V timeout -k 10 300 python3 tools/bench_train.py --batch $B --profile-only --steps 300 2>> $OUT/train_dx_chunks.err | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($B, 'chunks', $V, $R, round(d['ms_per_step'],4), round(d['parts_ms']['graph_device_ms'],4))" >> $OUT/train_dx_chunks.log \
+          || { echo "dxchunks $B $V FAILED" >> $OUT/commit.txt; tail -20 $OUT/train_dx_chunks.err; exit 1; }
+      done; done; done ;;
     rehearse5)   # the N > 1 launch path over a directory of configs[2]'s full size (100 000 files), FIVE ranks on ONE card (the box allows at most 6 processes on its GPU and the launcher counts: a 6-rank try was stopped by its process guard): a rehearsal (value null), never a measurement
       CATFISH_BENCH_DEVICE=0 CATFISH_DEVICE=0 CATFISH_RCCL_PROBE_TIMEOUT_S=60 timeout -k 10 1000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 5 \
         --master-addr 127.0.0.1 --master-port 29506 bench.py --gpus 5 --steps 20 --warmup 5 --reads-per-rank 20000 \
