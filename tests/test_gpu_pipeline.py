@@ -1054,6 +1054,42 @@ def test_rccl_probe_of_the_bench_succeeds_with_one_rank(tmp_path):
     assert res["ranks_seen"] == 1 and res["error"] is None, res
 
 
+@pytest.mark.timeout(600)
+def test_configs2_shard_at_full_per_rank_size(model, ckpt_weights):
+    """BASELINE configs[2] at ONE rank's full size -- 12 500 synthetic 4096-sample reads (seed 1, the reads `bench.py`'s sharded legs
+    use: 51 M samples, 700 x what the oracle classifies per second and core) -- through the sharded runner on the real engine.
+    Size-independent properties: (1) windows are independent, so how many reads share a launch must not matter: batches of 256 and
+    of 1100 reads give the same flat span table, bit for bit; (2) the blocks the 8-rank job would cut (`shard_contiguous`) tile the
+    list and a block classified on its own equals its rows of the whole; (3) every read has its true length and its spans lie
+    inside [-11, length + 16] in ascending order; plus an oracle sample of six reads (first / last of the list and of two blocks)."""
+    import bench
+    from catfish_amd import sharding
+    n = 12500
+    reads = [bench.squiggle_dac(np.random.default_rng([1, i]), bench.READ_LEN) for i in range(n)]
+    lengths = [bench.READ_LEN] * n
+    whole = sharding.infer_reads_sharded(model, reads, lengths=lengths, max_samples_per_batch=256 * bench.READ_LEN, as_table=True)
+    other = sharding.infer_reads_sharded(model, reads, lengths=lengths, max_samples_per_batch=1100 * bench.READ_LEN, as_table=True)
+    assert len(whole) == n and bool((whole.lengths == bench.READ_LEN).all())
+    for name in ("read_of", "start", "end", "lengths"):
+        assert np.array_equal(getattr(whole, name), getattr(other, name)), name
+    assert np.all(np.diff(whole.read_of) >= 0) and np.all(whole.start >= -11) and np.all(whole.end <= bench.READ_LEN + 16)
+    assert np.all(whole.end - whole.start >= 15 + 27)                                    # correct_short's 15 samples + the 11 / 16 extension
+    same_read = np.diff(whole.read_of) == 0
+    assert np.all(whole.start[1:][same_read] > whole.end[:-1][same_read] - 27)           # runs of one read ascend (extensions may overlap)
+    shards = sharding.shard_contiguous([sharding.windows_of(x) for x in lengths], 8)
+    assert [i for blk in shards for i in blk] == list(range(n)) and all(len(b) in (1562, 1563) for b in shards)
+    for r in (0, 7):
+        blk = shards[r]
+        alone = sharding.infer_reads_sharded(model, [reads[i] for i in blk], max_samples_per_batch=256 * bench.READ_LEN, as_table=True)
+        rows = (whole.read_of >= blk[0]) & (whole.read_of <= blk[-1])
+        assert np.array_equal(alone.read_of + blk[0], whole.read_of[rows])
+        assert np.array_equal(alone.start, whole.start[rows]) and np.array_equal(alone.end, whole.end[rows])
+    for i in (0, n - 1, shards[3][0], shards[3][-1], shards[7][0], 6250):
+        spans, length, _ = oracle.infer_read(oracle.normalize_raw_signal(reads[i]), ckpt_weights, np.float32)
+        assert whole.read(i) == (spans, length), i
+    assert len(whole.start) > n                                                          # the squiggles do hold homopolymer calls
+
+
 def test_configs1_at_full_size_is_invariant_to_the_launch_size(ckpt_weights):
     """BASELINE configs[1] at its full size -- 10 000 synthetic 4096-sample reads, fp32 -- which the oracle cannot follow
     (it classifies ~75 k samples/s per core; this is 41 M): windows are independent, so how many reads share a launch must
