@@ -86,15 +86,21 @@ static int listing_split(const cf_listing* l, int64_t lo, int64_t hi, const int6
     }
     group_at.push_back(todo.size());
     const int64_t n_groups = (int64_t)group_at.size() - 1;
-    const int in_fd = open(l->dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
-    const int hp_fd = open(hp_dir, O_RDONLY | O_DIRECTORY | O_CLOEXEC);
-    const int non_fd = open(non_dir, O_RDONLY | O_DIRECTORY | O_CLOEXEC);
-    const int open_errno = errno;
+    int open_errno = 0;
+    const char* unopened = nullptr;
+    auto open_dir = [&](const char* path) {
+        const int fd = open(path, O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+        if (fd < 0 && !unopened) { open_errno = errno; unopened = path; }
+        return fd;
+    };
+    const int in_fd = open_dir(l->dir.c_str());
+    const int hp_fd = open_dir(hp_dir);
+    const int non_fd = open_dir(non_dir);
     auto close_all = [&] { if (in_fd >= 0) close(in_fd); if (hp_fd >= 0) close(hp_fd); if (non_fd >= 0) close(non_fd); };
-    if (in_fd < 0 || hp_fd < 0 || non_fd < 0) {
+    if (unopened) {
+        const std::string msg = std::string("cf_listing_split_npy_int16: cannot open ") + unopened + ": " + strerror(open_errno);
         close_all();
-        return fail(CF_ERR_IO, std::string("cf_listing_split_npy_int16: cannot open ") + (in_fd < 0 ? l->dir.c_str() : hp_fd < 0 ? hp_dir : non_dir) +
-                                   ": " + strerror(open_errno));
+        return fail(CF_ERR_IO, msg);
     }
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 4, std::min<int64_t>(n_groups, 64)));
     std::vector<cf_split::Failure> failed((size_t)nt);
@@ -109,50 +115,50 @@ static int listing_split(const cf_listing* l, int64_t lo, int64_t hi, const int6
                 for (;;) {
                     const int64_t g = next.fetch_add(1);
                     if (g >= n_groups || stop.load()) break;
-                  for (size_t k = group_at[(size_t)g]; k < group_at[(size_t)g + 1] && bad.read < 0; ++k) {
-                    const int64_t r = todo[k];
-                    const char* nm = l->blob.data() + l->at[(size_t)(lo + r)];
-                    cf_loader::Item it;
-                    if (!cf_loader::slurp(in_fd, nm, it)) {
-                        bad.read = r; bad.kind = 1;
-                        bad.what = std::string("not a readable one-dimensional little-endian int16 .npy: ") + nm;
-                        stop.store(true);
-                        break;
-                    }
-                    const int16_t* sig = reinterpret_cast<const int16_t*>(it.bytes.data() + it.data_off);
-                    const char* dot = strchr(nm, '.');
-                    const std::string stem(nm, dot ? (size_t)(dot - nm) : strlen(nm));
-                    int64_t index = 0;
-                    for (int part = 0; part < 2 && bad.read < 0; ++part) {
-                        const int64_t* bounds = part ? non_bounds : hp_bounds;
-                        const int64_t* st = part ? non_start : hp_start;
-                        const int64_t* en = part ? non_end : hp_end;
-                        for (int64_t row = bounds[r]; row < bounds[r + 1]; ++row, ++index) {
-                            int64_t a, b;
-                            cf_split::slice_bounds(st[row], en[row], it.count, a, b);
-                            char head[192];
-                            const size_t hl = cf_split::npy_header(b - a, head);
-                            out.resize(hl + 2 * (size_t)(b - a));
-                            memcpy(out.data(), head, hl);
-                            if (b > a) memcpy(out.data() + hl, sig + a, 2 * (size_t)(b - a));
-                            const std::string dest = stem + "_" + std::to_string(index) + ".npy";
-                            const int fd = openat(part ? non_fd : hp_fd, dest.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
-                            bool ok = fd >= 0;
-                            int err = ok ? 0 : errno;
-                            if (ok && !cf_split::write_all(fd, out.data(), out.size())) { ok = false; err = errno; }
-                            if (fd >= 0 && close(fd) != 0 && ok) { ok = false; err = errno; }
-                            if (!ok) {
-                                bad.read = r; bad.kind = 2;
-                                bad.what = std::string(part ? non_dir : hp_dir) + "/" + dest + ": " + strerror(err);
-                                stop.store(true);
-                                break;
-                            }
-                            done[(size_t)t][1 + part] += 1;
-                            done[(size_t)t][3] += b - a;
+                    for (size_t k = group_at[(size_t)g]; k < group_at[(size_t)g + 1] && bad.read < 0; ++k) {
+                        const int64_t r = todo[k];
+                        const char* nm = l->blob.data() + l->at[(size_t)(lo + r)];
+                        cf_loader::Item it;
+                        if (!cf_loader::slurp(in_fd, nm, it)) {
+                            bad.read = r; bad.kind = 1;
+                            bad.what = std::string("not a readable one-dimensional little-endian int16 .npy: ") + nm;
+                            stop.store(true);
+                            break;
                         }
+                        const int16_t* sig = reinterpret_cast<const int16_t*>(it.bytes.data() + it.data_off);
+                        const char* dot = strchr(nm, '.');
+                        const std::string stem(nm, dot ? (size_t)(dot - nm) : strlen(nm));
+                        int64_t index = 0;
+                        for (int part = 0; part < 2 && bad.read < 0; ++part) {
+                            const int64_t* bounds = part ? non_bounds : hp_bounds;
+                            const int64_t* st = part ? non_start : hp_start;
+                            const int64_t* en = part ? non_end : hp_end;
+                            for (int64_t row = bounds[r]; row < bounds[r + 1]; ++row, ++index) {
+                                int64_t a, b;
+                                cf_split::slice_bounds(st[row], en[row], it.count, a, b);
+                                char head[192];
+                                const size_t hl = cf_split::npy_header(b - a, head);
+                                out.resize(hl + 2 * (size_t)(b - a));
+                                memcpy(out.data(), head, hl);
+                                if (b > a) memcpy(out.data() + hl, sig + a, 2 * (size_t)(b - a));
+                                const std::string dest = stem + "_" + std::to_string(index) + ".npy";
+                                const int fd = openat(part ? non_fd : hp_fd, dest.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+                                bool ok = fd >= 0;
+                                int err = ok ? 0 : errno;
+                                if (ok && !cf_split::write_all(fd, out.data(), out.size())) { ok = false; err = errno; }
+                                if (fd >= 0 && close(fd) != 0 && ok) { ok = false; err = errno; }
+                                if (!ok) {
+                                    bad.read = r; bad.kind = 2;
+                                    bad.what = std::string(part ? non_dir : hp_dir) + "/" + dest + ": " + strerror(err);
+                                    stop.store(true);
+                                    break;
+                                }
+                                done[(size_t)t][1 + part] += 1;
+                                done[(size_t)t][3] += b - a;
+                            }
+                        }
+                        if (bad.read < 0) done[(size_t)t][0] += 1;
                     }
-                    if (bad.read < 0) done[(size_t)t][0] += 1;
-                  }
                 }
             } catch (const std::bad_alloc&) {                   // a thread may not throw
                 bad.read = 0; bad.kind = 3; bad.what = "out of host memory";
